@@ -1,0 +1,174 @@
+/*
+ * swmi.h -- C ABI of the MI355X-native batched Smith-Waterman scorer (libswmi.so).
+ *
+ * Drop-in boundary for ONE path of eukaryo/smith-waterman-simd: the fixed-shape
+ * (128 x 128, 2-bit alphabet held one base per byte, 4x4 int8 score matrix, linear gap,
+ * score only) Smith-Waterman scorer.  The reference has no FFI layer; its boundary is
+ * the free-function signature
+ *
+ *     int SmithWaterman_simdN(const std::array<uint8_t,128>& seq1,
+ *                             const std::array<uint8_t,128>& seq2,
+ *                             const std::array<int8_t,16>&  score_matrix,
+ *                             const int8_t gap_penalty);
+ *
+ * (source.cpp:35-39 scalar, :462-466 simd4, :758-762 simd7, :953-957 simd9).  Every entry
+ * point below cites the reference interface it replaces.  Semantics are those of the
+ * scalar SmithWaterman (source.cpp:49-53) in int32:
+ *
+ *     H(i,j) = max(0, H(i-1,j-1) + sm[seq1[i-1]*4 + seq2[j-1]], H(i-1,j) - gap, H(i,j-1) - gap)
+ *     score  = max over the 128 x 128 cells
+ *
+ * Valid domain (bit-exact with the reference scalar, and with simd..simd8 wherever those
+ * are themselves valid): every score_matrix entry in [-128,127], gap_penalty in [0,127].
+ * Bases are taken modulo 4 (the reference indexes out of range for bases >= 4).
+ * gap_penalty < 0 is rejected with SWMI_ERR_DOMAIN.
+ *
+ * There is NO CPU fallback: every scoring entry point runs hand-written gfx950 HIP kernels
+ * and fails with an error code when no MI355X-class (gfx950) device is usable.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.
+ */
+#ifndef SWMI_H
+#define SWMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SWMI_API __attribute__((visibility("default")))
+#else
+#define SWMI_API
+#endif
+
+#define SWMI_SEQ_LEN 128        /* std::array<uint8_t,128>, source.cpp:463-464 */
+#define SWMI_PACKED_LEN 32      /* std::array<uint8_t,32>,  source.cpp:1580     */
+#define SWMI_VERSION 100
+
+enum swmi_status {
+    SWMI_OK = 0,
+    SWMI_ERR_NOT_INITIALIZED = -1,
+    SWMI_ERR_NO_DEVICE = -2,         /* no HIP device / HIP runtime unusable            */
+    SWMI_ERR_UNSUPPORTED_ARCH = -3,  /* device is not gfx950                             */
+    SWMI_ERR_INVALID_ARGUMENT = -4,  /* NULL pointer, bad size, unknown schedule ...     */
+    SWMI_ERR_DOMAIN = -5,            /* gap_penalty < 0                                  */
+    SWMI_ERR_ALIGNMENT = -6,         /* device pointer not 16-byte aligned               */
+    SWMI_ERR_HIP = -7,               /* a HIP call failed; text in swmi_last_error()     */
+    SWMI_ERR_QUEUE_FULL = -8
+};
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+
+/* Bind the calling process to one GPU (one process per GPU; device = ordinal as seen by
+ * HIP, or -1 for "LOCAL_RANK env var if set, else 0").  Creates the library's streams and
+ * workspace.  Idempotent for the same device.  The reference has no counterpart (it is a
+ * single-threaded CPU program, source.cpp:3275-3301). */
+SWMI_API int swmi_init(int device);
+SWMI_API int swmi_shutdown(void);
+/* Text of the last error on the calling thread ("" if none). Never NULL. */
+SWMI_API const char *swmi_last_error(void);
+SWMI_API int swmi_version(void);
+
+/* ---- scoring ------------------------------------------------------------------------ */
+
+/* Replaces a call to SmithWaterman / SmithWaterman_simd .. _simd9
+ * (source.cpp:35-39, :462-466, :758-762, :953-957; call sites :2961-2970, :3077, :3212).
+ * std::array<>::data() passes straight through.  Synchronous: one launch per call, so it
+ * is correct but launch-latency bound -- use the batch or queue entry points for
+ * throughput.  Returns the score (>= 0) or a negative swmi_status. */
+SWMI_API int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq2[SWMI_SEQ_LEN],
+                             const int8_t score_matrix[16], int8_t gap_penalty);
+
+/* The reference's 1M-call loop (source.cpp:3074-3082: `for 1,000,000: score = simd4(a,b,sm,gap)`)
+ * as ONE call: pair k is the 128 bytes at seq1s + 128*k and seq2s + 128*k (the per-pair
+ * layout of std::array<uint8_t,128>, concatenated).  Host buffers; the library stages them
+ * through pinned memory in chunks, overlapping H2D copy, kernel and D2H copy.
+ * scores[k] receives what SmithWaterman(seq1_k, seq2_k, score_matrix, gap) returns.
+ * n may be 0.  Returns SWMI_OK or a negative swmi_status. */
+SWMI_API int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n,
+                              const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+
+/* Same contract with all three buffers already resident in device memory (16-byte aligned
+ * device pointers; `stream` is a hipStream_t or NULL for the library's own stream).
+ * Asynchronous: returns after the launch; the caller synchronises the stream.  This is the
+ * entry bench.py times (inputs resident in HBM). */
+SWMI_API int swmi_score_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n,
+                                     const int8_t score_matrix[16], int8_t gap_penalty,
+                                     void *d_scores, void *stream);
+
+/* One-vs-many shape of SmithWaterman_8b111x32mark1/2/3 (source.cpp:1227-1230: 32 seq1 x one
+ * seq2 -> int[32]) generalised to n_seq1 sequences and arbitrary parameters:
+ * scores[k] = SmithWaterman(seq1s + 128*k, seq2, sm, gap).  Host buffers. */
+SWMI_API int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t seq2[SWMI_SEQ_LEN],
+                                    const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+
+/* 2-bit packed inputs in the reference's own wire format (unpack(), source.cpp:1580-1583:
+ * base k of byte i = (src[i] >> 2k) & 3): pair k is the 32 bytes at seq1s_packed + 32*k.
+ * The kernel unpacks on the fly (no unpacked copy in HBM).  Host buffers. */
+SWMI_API int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_packed, size_t n,
+                                     const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+SWMI_API int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq2s_packed, size_t n,
+                                            const int8_t score_matrix[16], int8_t gap_penalty,
+                                            void *d_scores, void *stream);
+
+/* unpack() itself (source.cpp:1580-1583) for n packed sequences, on the GPU. Host buffers. */
+SWMI_API int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked);
+
+/* ---- deferred queue behind the per-pair signature -------------------------------------
+ * Lets a per-pair caller (the reference's timing loop) keep its call shape while the
+ * library batches: submit() copies the pair into pinned staging memory and returns its
+ * ticket (0,1,2,...); full staging blocks are shipped to the GPU asynchronously;
+ * swmi_queue_wait() drains everything and exposes scores[ticket]. */
+typedef struct swmi_queue swmi_queue;
+SWMI_API int swmi_queue_create(size_t max_pairs, const int8_t score_matrix[16], int8_t gap_penalty,
+                               swmi_queue **out);
+SWMI_API long long swmi_queue_submit(swmi_queue *q, const uint8_t seq1[SWMI_SEQ_LEN],
+                                     const uint8_t seq2[SWMI_SEQ_LEN]);
+SWMI_API int swmi_queue_wait(swmi_queue *q, const int32_t **scores, size_t *n_scores);
+SWMI_API int swmi_queue_reset(swmi_queue *q);
+SWMI_API int swmi_queue_destroy(swmi_queue *q);
+
+/* ---- schedules ------------------------------------------------------------------------
+ * The reference ships nine schedules of one semantics (simd .. simd9).  So does this
+ * library: `lanes_per_alignment` L in {64,32,16,8,4,2} lanes of a 64-lane wavefront walk one
+ * alignment's anti-diagonal (each lane owns 128/L consecutive rows); L = 64 is literally
+ * "one wavefront per alignment".  0 selects the default (fastest measured).
+ * flags: bit 0 = disable the gap-folded cell body; bit 1 = 16-bit-max cell body (both: same results). */
+SWMI_API int swmi_set_schedule(int lanes_per_alignment, unsigned flags);
+SWMI_API int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags);
+
+/* ---- synthetic inputs ----------------------------------------------------
+ * Counter-based generator, identical on host and device: pair p, sequence s (0/1), 64-bit
+ * word w (0..3): x = splitmix64(seed ^ ((p*2+s)*4+w) * 0x9E3779B97F4A7C15); base k of the
+ * word = (x >> 2k) & 3.  Stands in for the reference's mt19937_64 + uniform_int_distribution
+ * draw (source.cpp:3033-3040), which is implementation-defined across standard libraries. */
+SWMI_API int swmi_generate_pairs_device(void *d_seq1s, void *d_seq2s, size_t n, uint64_t seed,
+                                        uint64_t first_pair, void *stream);
+SWMI_API int swmi_generate_pairs_host(uint8_t *seq1s, uint8_t *seq2s, size_t n, uint64_t seed,
+                                      uint64_t first_pair);
+
+/* ---- measurement ----------------------------------------------------------------------
+ * Launches the batch kernel `iters` times back to back on `stream` (or the library stream)
+ * bracketed by hipEvents on that same stream and returns the average per-launch duration. */
+SWMI_API int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n,
+                                    const int8_t score_matrix[16], int8_t gap_penalty,
+                                    void *d_scores, void *stream, int iters, float *avg_ms);
+
+typedef struct swmi_device_info {
+    int device;
+    int compute_units;
+    int clock_khz;
+    int wavefront_size;
+    size_t hbm_bytes;
+    char arch[64];
+    char name[128];
+} swmi_device_info;
+SWMI_API int swmi_get_device_info(swmi_device_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWMI_H */

@@ -1,0 +1,390 @@
+// sw_kernels.hip -- hand-written gfx950 (CDNA4, MI355X) kernels for the fixed-shape Smith-Waterman scorer.
+//
+// Semantics: the reference scalar recurrence (source.cpp:49-53)
+//     H(i,j) = max(0, H(i-1,j-1) + sm[seq1[i-1]*4 + seq2[j-1]], H(i-1,j) - gap, H(i,j-1) - gap)
+//     score  = max over the 128 x 128 cells
+// This is NOT a translation of the reference's AVX2 parallelogram (source.cpp:462-571). The design is
+// driven by what the gfx950 VALU issues at full rate (tools/microbench/valu_rate*.hip):
+//
+//   * A 64-lane wavefront walks the anti-diagonals of 64/L alignments at once: L lanes per alignment,
+//     lane j of a group owns the R = 128/L consecutive rows j*R .. j*R+R-1 and, at step t, computes the
+//     R cells of column c = t - j (top to bottom).  L = 64 is literally "one wavefront per alignment";
+//     smaller L trades lanes-in-flight for a shorter pipeline fill (L-1 idle steps of 128+L-1) and fewer
+//     cross-lane moves per cell.
+//   * The vertical/diagonal dependency between neighbouring lanes is one DPP lane shift per step
+//     (v_mov_b32_dpp / v_and_b32_dpp row_shr:1 or wave_shr:1 -- what __shfl_up(v,1) should be on gfx9;
+//     the compiler lowers __shfl_up to ds_bpermute_b32, which costs an LDS round trip).
+//   * The query profile lives in LDS: for every column of seq2 a one-hot dword (1 << 8*base).  A lane reads
+//     the profile entry of its current column with one ds_read_b32 per step; out-of-range columns hit zero pads,
+//     which makes pipeline fill/drain steps harmless without any predication.
+//   * The score lookup AND the diagonal add are ONE instruction: v_dot4c_i32_i8 acc=H(i-1,j-1),
+//     a = the row's 4 int8 scores, b = the column's one-hot.
+//   * max() runs on v_max_i16 (full rate on gfx950; v_max_i32 / v_max3_i32 are half rate). All H values fit
+//     in 15 bits (<= 128*127), t = H + s fits int16.
+//
+// Two cell bodies, identical results:
+//   general : t = dot4c(row, onehot, diag); m = max(left, up); mg = sat_sub(m, gap); h = max(mg, t)
+//   folded  : rows carry s + gap (host folds when every s + gap fits int8):
+//             x = max(left, up, dot4c(row', onehot, diag)); h = sat_sub(x, gap); best tracks x
+#include "swmi_internal.h"
+
+namespace swmi {
+namespace {
+
+constexpr int kSeqLen = 128;
+constexpr int kWavesPerBlock = 4;
+
+// ---- small device helpers -----------------------------------------------------------------------
+
+__device__ __forceinline__ int max_i16(int a, int b)
+{
+    // v_max_i16: full rate on gfx950 (v_max_i32 / v_max3_i32 are half rate).  Inputs are read as their low
+    // 16 bits, the result is zero-extended (gfx9 16-bit VALU ops clear dst[31:16]).  Expressed through the
+    // compiler (not inline asm) so that the hazard recogniser keeps the wait states a VALU read of a
+    // v_dot4 result needs -- an asm v_max_i16 placed right behind v_dot4c reads a stale register.
+    const short r = __builtin_elementwise_max((short)a, (short)b);
+    return (int)(unsigned short)r;
+}
+
+template <bool I16>
+__device__ __forceinline__ int vmax(int a, int b)
+{
+    if constexpr (I16) return max_i16(a, b);
+    else return a > b ? a : b;
+}
+
+template <bool I16>
+__device__ __forceinline__ int sat_sub(int a, int b)   // max(a - b, 0) for 0 <= a, b < 2^15 : v_sub_u16 / v_sub_u32 ... clamp (full rate)
+{
+    if constexpr (I16) return (int)(unsigned short)__builtin_elementwise_sub_sat((unsigned short)a, (unsigned short)b);
+    else return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b);
+}
+
+// Opaque to the optimiser, free at run time: stops hipcc from re-associating two full-rate v_max_i16 into one
+// quarter-rate v_max3_i16 (8 clk per wave64 on gfx950 against 2 x 2.25).
+__device__ __forceinline__ int keep(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Value of the same register in lane-1 of the group (0 for the first lane of a group).
+template <int L>
+__device__ __forceinline__ int from_prev_lane(int v, int group_mask)
+{
+    if constexpr (L == 64) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    } else if constexpr (L == 32) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true) & group_mask;
+    } else if constexpr (L == 16) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    } else {
+        return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true) & group_mask;
+    }
+}
+
+// R one-byte bases -> NW dwords, 4 bases per dword
+template <int R>
+__device__ __forceinline__ void load_bases(const uint8_t *p, uint32_t (&w)[(R + 3) / 4])
+{
+    if constexpr (R == 2) {
+        w[0] = *reinterpret_cast<const uint16_t *>(p);
+    } else if constexpr (R == 4) {
+        w[0] = *reinterpret_cast<const uint32_t *>(p);
+    } else if constexpr (R == 8) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        w[0] = v.x; w[1] = v.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R / 16; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + 16 * k);
+            w[4 * k + 0] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+    }
+}
+
+// 8 bits holding four 2-bit bases (LSB first, source.cpp:1581) -> dword with one base per byte
+__device__ __forceinline__ uint32_t spread4(uint32_t v)
+{
+    return (v | (v << 6) | (v << 12) | (v << 18)) & 0x03030303u;
+}
+
+// R two-bit bases (R/4 bytes at p) -> NW dwords, one base per byte
+template <int R>
+__device__ __forceinline__ void load_bases_packed(const uint8_t *p, uint32_t (&w)[(R + 3) / 4])
+{
+    if constexpr (R == 2) {
+        // half a nibble: lane j of 64 owns bases 2j, 2j+1 -> byte j/2, bit offset 4*(j&1); caller passes p = byte address
+        w[0] = 0;  // handled by caller (needs lane parity); see sw128_kernel
+    } else if constexpr (R == 4) {
+        w[0] = spread4(p[0]);
+    } else if constexpr (R == 8) {
+        const uint32_t v = *reinterpret_cast<const uint16_t *>(p);
+        w[0] = spread4(v & 0xff); w[1] = spread4(v >> 8);
+    } else if constexpr (R == 16) {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = spread4((v >> (8 * k)) & 0xff);
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 32; ++q) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p + 8 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w[8 * q + k] = spread4((v.x >> (8 * k)) & 0xff);
+                w[8 * q + 4 + k] = spread4((v.y >> (8 * k)) & 0xff);
+            }
+        }
+    }
+}
+
+// ---- the scoring kernel -------------------------------------------------------------------------
+//
+// MODE 0: pair k = 128 B at seq1s + 128k / seq2s + 128k   (swmi_score_batch*)
+// MODE 1: 2-bit packed, pair k = 32 B at + 32k            (swmi_score_batch_packed*)
+// MODE 2: one-vs-many: seq1 k at seq1s + 128k, ONE seq2    (swmi_score_one_vs_many)
+template <int L, bool FOLD, bool I16, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
+             uint32_t n, SmRows rows, int gap)
+{
+    constexpr int R = kSeqLen / L;          // rows per lane
+    constexpr int A = 64 / L;               // alignments per wavefront
+    constexpr int PAD = L < 4 ? 4 : L;      // zero profile entries either side of the 128 columns
+    constexpr int S = kSeqLen + 2 * PAD;    // profile entries per alignment
+    constexpr int T = kSeqLen + L - 1;      // anti-diagonal steps
+    constexpr int NW = (R + 3) / 4;
+
+    __shared__ uint32_t lds_profile[kWavesPerBlock][A * S];   // one-hot query profile (seq2), per wave
+    __shared__ uint32_t lds_rows[kWavesPerBlock][4];          // score-matrix rows, per wave
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = lane / L;                 // alignment slot inside the wave
+    const int j = lane % L;                 // lane inside the group
+    const uint32_t first_pair = (blockIdx.x * kWavesPerBlock + wv) * A;
+    if (first_pair >= n) return;            // wave-uniform: only wave-level synchronisation below
+    uint32_t pair = first_pair + g;
+    const bool live = pair < n;
+    if (!live) pair = n - 1;                // ragged tail: recompute the last pair, do not store
+
+    // ---- load this lane's R rows of seq1 and its R columns of seq2 (coalesced: lane * R bytes) ----
+    uint32_t a_w[NW], b_w[NW];
+    if constexpr (MODE == 1) {
+        if constexpr (R == 2) {
+            const uint32_t sh = 4 * (j & 1);
+            a_w[0] = spread4((seq1s[(size_t)pair * 32 + (j >> 1)] >> sh) & 0xf);
+            b_w[0] = spread4((seq2s[(size_t)pair * 32 + (j >> 1)] >> sh) & 0xf);
+        } else {
+            load_bases_packed<R>(seq1s + (size_t)pair * 32 + j * (R / 4), a_w);
+            load_bases_packed<R>(seq2s + (size_t)pair * 32 + j * (R / 4), b_w);
+        }
+    } else {
+        load_bases<R>(seq1s + (size_t)pair * kSeqLen + j * R, a_w);
+        load_bases<R>(seq2s + (MODE == 2 ? (size_t)0 : (size_t)pair * kSeqLen) + j * R, b_w);
+    }
+
+    // ---- stage the score-matrix rows and the one-hot query profile in LDS ------------------------
+    if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
+    uint32_t *prof = &lds_profile[wv][g * S];
+    for (int k = j; k < PAD; k += L) {
+        prof[k] = 0;
+        prof[PAD + kSeqLen + k] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint32_t b = (b_w[i / 4] >> (8 * (i % 4))) & 3u;
+        prof[PAD + j * R + i] = 1u << (8 * b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    int row_scores[R];                      // 4 x int8 (sm[a_i][0..3], + gap when FOLD) per owned row
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint32_t a = (a_w[i / 4] >> (8 * (i % 4))) & 3u;
+        row_scores[i] = (int)lds_rows[wv][a];
+    }
+
+    // ---- anti-diagonal sweep ------------------------------------------------------------------------
+    int h[R];                               // h[i] = H(row i, previous column)
+#pragma unroll
+    for (int i = 0; i < R; ++i) h[i] = 0;
+    int best = 0;
+    int up_in = 0;                          // H(last row of lane j-1, this column)
+    int diag_in = 0;                        // H(last row of lane j-1, previous column)
+    const int group_mask = j == 0 ? 0 : -1;
+    const uint32_t *col = prof + PAD - j;   // col[t] = profile entry of column t - j
+    uint32_t onehot_next = col[0];
+
+    for (int t = 0; t < T; ++t) {
+        const int onehot = (int)onehot_next;
+        onehot_next = col[t + 1];
+        int up = up_in;
+        // Phase 1: every diagonal term of this column, t[i] = H(i-1, c-1) + s(i, c) (+ gap), from the OLD column
+        // values (all still live, so the compiler picks the 3-address v_dot4_i32_i8 and needs no copies).
+        int tsum[R];
+        tsum[0] = __builtin_amdgcn_sdot4(row_scores[0], onehot, diag_in, false);
+#pragma unroll
+        for (int i = 1; i < R; ++i) tsum[i] = __builtin_amdgcn_sdot4(row_scores[i], onehot, h[i - 1], false);
+        diag_in = up_in;
+        // Phase 2: the top-to-bottom chain through `up`.
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            int hn;
+            if constexpr (FOLD) {
+                const int lu = h[i] > up ? h[i] : up;
+                const int x = lu > tsum[i] ? lu : tsum[i];                  // v_max3_i32 (half rate, two maxes)
+                best = I16 ? keep(max_i16(best, x)) : vmax<false>(best, x);
+                hn = sat_sub<I16>(x, gap);
+            } else if constexpr (I16) {
+                const int m = keep(max_i16(h[i], up));
+                hn = keep(max_i16(sat_sub<true>(m, gap), tsum[i]));
+                best = keep(max_i16(best, hn));
+            } else {
+                const int m = vmax<false>(h[i], up);
+                hn = vmax<false>(sat_sub<false>(m, gap), tsum[i]);
+                best = vmax<false>(best, hn);
+            }
+            h[i] = hn;
+            up = hn;
+        }
+        up_in = from_prev_lane<L>(up, group_mask);
+    }
+
+    // ---- reduce over the L lanes of the group, one int32 per alignment ------------------------------
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+        const int other = __shfl_xor(best, o);
+        best = best > other ? best : other;
+    }
+    if constexpr (FOLD) best = best > gap ? best - gap : 0;
+    if (j == 0 && live) scores[pair] = best;
+}
+
+// ---- synthetic input generator (specification in include/swmi.h) -----------------------------------
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one thread = one 64-bit word = 32 bases = 32 output bytes
+__global__ void __launch_bounds__(256)
+generate_kernel(uint8_t *__restrict__ seq1s, uint8_t *__restrict__ seq2s, uint64_t n_words, uint64_t seed,
+                uint64_t first_pair)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_words; id += stride) {
+        const uint64_t w = id & 3, s = (id >> 2) & 1, k = id >> 3;
+        const uint64_t ctr = ((first_pair + k) * 2 + s) * 4 + w;
+        const uint64_t x = splitmix64(seed ^ (ctr * 0x9E3779B97F4A7C15ull));
+        uint4 lo, hi;
+        lo.x = spread4((uint32_t)(x >> 0) & 0xff);  lo.y = spread4((uint32_t)(x >> 8) & 0xff);
+        lo.z = spread4((uint32_t)(x >> 16) & 0xff); lo.w = spread4((uint32_t)(x >> 24) & 0xff);
+        hi.x = spread4((uint32_t)(x >> 32) & 0xff); hi.y = spread4((uint32_t)(x >> 40) & 0xff);
+        hi.z = spread4((uint32_t)(x >> 48) & 0xff); hi.w = spread4((uint32_t)(x >> 56) & 0xff);
+        uint4 *dst = reinterpret_cast<uint4 *>((s ? seq2s : seq1s) + k * kSeqLen + w * 32);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+// unpack() of source.cpp:1580-1583 for n sequences: one thread = 4 packed bytes -> 16 output bytes
+__global__ void __launch_bounds__(256)
+unpack_kernel(const uint8_t *__restrict__ packed, uint8_t *__restrict__ unpacked, uint64_t n_words)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_words; id += stride) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(packed)[id];
+        uint4 o;
+        o.x = spread4(v & 0xff); o.y = spread4((v >> 8) & 0xff);
+        o.z = spread4((v >> 16) & 0xff); o.w = spread4(v >> 24);
+        reinterpret_cast<uint4 *>(unpacked)[id] = o;
+    }
+}
+
+template <int L, int MODE>
+hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s2, int32_t *out, size_t n,
+                    const SmRows &rows, int gap, hipStream_t stream)
+{
+    constexpr int A = 64 / L;
+    const size_t waves = (n + A - 1) / A;
+    const size_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7fffffffull || n > 0xffffffffull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+    const uint32_t n32 = (uint32_t)n;
+    if (cfg.fold_gap) {
+        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, true, true, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+        else             hipLaunchKernelGGL((sw128_kernel<L, true, false, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+    } else {
+        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, false, true, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+        else             hipLaunchKernelGGL((sw128_kernel<L, false, false, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+    }
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_mode(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s2, int32_t *out, size_t n,
+                       const SmRows &rows, int gap, hipStream_t stream)
+{
+    switch (cfg.lanes_per_alignment) {
+    case 64: return launch_L<64, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    case 32: return launch_L<32, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    case 16: return launch_L<16, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    case 8:  return launch_L<8, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    case 4:  return launch_L<4, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    case 2:  return launch_L<2, MODE>(cfg, s1, s2, out, n, rows, gap, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+bool schedule_supported(int L)
+{
+    return L == 64 || L == 32 || L == 16 || L == 8 || L == 4 || L == 2;
+}
+
+hipError_t launch_score(const LaunchConfig &cfg, const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores,
+                        size_t n, const SmRows &rows, int gap, bool packed, hipStream_t stream)
+{
+    // a launch covers at most 2^31 pairs; larger batches are split by the caller
+    return packed ? launch_mode<1>(cfg, d_seq1s, d_seq2s, d_scores, n, rows, gap, stream)
+                  : launch_mode<0>(cfg, d_seq1s, d_seq2s, d_scores, n, rows, gap, stream);
+}
+
+hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_seq1s, const uint8_t *d_seq2,
+                                    int32_t *d_scores, size_t n_seq1, const SmRows &rows, int gap, hipStream_t stream)
+{
+    return launch_mode<2>(cfg, d_seq1s, d_seq2, d_scores, n_seq1, rows, gap, stream);
+}
+
+hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,
+                           hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t n_words = (uint64_t)n * 8;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(generate_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_seq1s, d_seq2s, n_words, seed,
+                       first_pair);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const uint8_t *d_packed, uint8_t *d_unpacked, size_t n_seqs, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    const uint64_t n_words = (uint64_t)n_seqs * 8;   // 32 packed bytes = 8 dwords per sequence
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_packed, d_unpacked, n_words);
+    return hipGetLastError();
+}
+
+}  // namespace swmi

@@ -1,0 +1,537 @@
+// swmi_api.cpp -- host side of libswmi.so: the C ABI of include/swmi.h over the gfx950 kernels.
+//
+// Host responsibilities only: argument checking, score-matrix packing, chunked H2D / kernel / D2H
+// pipelining for host-resident batches, the deferred queue behind the per-pair signature, and
+// hipEvent timing.  There is deliberately no CPU implementation of the scoring path in this
+// library: without a usable gfx950 device every scoring entry point returns an error.
+#include "../../include/swmi.h"
+#include "swmi_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+using swmi::LaunchConfig;
+using swmi::SmRows;
+
+thread_local char t_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_error, sizeof t_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SWMI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kSeq = SWMI_SEQ_LEN;
+constexpr size_t kChunkPairs = size_t(1) << 20;      // host-batch pipeline granule: 1M pairs = 128 MiB per input array
+constexpr size_t kMaxLaunchPairs = size_t(1) << 30;  // pairs per kernel launch (kernel indexes pairs with uint32)
+constexpr int kSlots = 2;
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
+    int32_t *d_scores = nullptr;
+    size_t capacity = 0;   // pairs
+};
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipDeviceProp_t prop{};
+    hipStream_t stream = nullptr;       // library stream for *_device entry points called with stream == NULL
+    Slot slots[kSlots];
+    int lanes = 8;                      // default schedule
+    unsigned flags = 0;
+    std::mutex mu;                      // serialises use of the slots
+};
+
+Context g_ctx;
+std::mutex g_init_mu;
+
+int check_ready()
+{
+    if (!g_ctx.ready) return fail(SWMI_ERR_NOT_INITIALIZED, "swmi_init() has not been called (or failed)");
+    return SWMI_OK;
+}
+
+int check_params(const int8_t *sm, int gap)
+{
+    if (!sm) return fail(SWMI_ERR_INVALID_ARGUMENT, "score_matrix is NULL");
+    if (gap < 0) return fail(SWMI_ERR_DOMAIN, "gap_penalty %d < 0 is outside the supported domain [0,127]", gap);
+    return SWMI_OK;
+}
+
+// rows.r[a] = sm[a*4 + 0..3] (+ gap when folded), one int8 per byte
+SmRows pack_rows(const int8_t *sm, int add)
+{
+    SmRows rows;
+    for (int a = 0; a < 4; ++a) {
+        uint32_t r = 0;
+        for (int b = 0; b < 4; ++b) r |= uint32_t(uint8_t(int8_t(sm[4 * a + b] + add))) << (8 * b);
+        rows.r[a] = r;
+    }
+    return rows;
+}
+
+// Choose the cell body: the gap-folded recurrence needs every sm + gap to fit int8.
+LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows)
+{
+    LaunchConfig cfg;
+    cfg.lanes_per_alignment = g_ctx.lanes;
+    cfg.use_i16 = (g_ctx.flags & swmi::kUseI16) != 0;
+    bool fold = !(g_ctx.flags & swmi::kNoGapFold);
+    for (int k = 0; k < 16 && fold; ++k) {
+        const int v = int(sm[k]) + gap;
+        if (v < -128 || v > 127) fold = false;
+    }
+    cfg.fold_gap = fold;
+    *rows = pack_rows(sm, fold ? gap : 0);
+    return cfg;
+}
+
+int ensure_slot(Slot &s, size_t pairs)
+{
+    if (s.capacity >= pairs) return SWMI_OK;
+    if (s.d_seq1) { (void)hipFree(s.d_seq1); s.d_seq1 = nullptr; }
+    if (s.d_seq2) { (void)hipFree(s.d_seq2); s.d_seq2 = nullptr; }
+    if (s.d_scores) { (void)hipFree(s.d_scores); s.d_scores = nullptr; }
+    s.capacity = 0;
+    HIP_TRY(hipMalloc(&s.d_seq1, pairs * kSeq));
+    HIP_TRY(hipMalloc(&s.d_seq2, pairs * kSeq));
+    HIP_TRY(hipMalloc(&s.d_scores, pairs * sizeof(int32_t)));
+    s.capacity = pairs;
+    return SWMI_OK;
+}
+
+int launch_device(const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out, hipStream_t st,
+                  bool packed)
+{
+    SmRows rows;
+    const LaunchConfig cfg = make_config(sm, gap, &rows);
+    const size_t stride = packed ? SWMI_PACKED_LEN : kSeq;
+    for (size_t off = 0; off < n; off += kMaxLaunchPairs) {
+        const size_t m = n - off < kMaxLaunchPairs ? n - off : kMaxLaunchPairs;
+        HIP_TRY(swmi::launch_score(cfg, static_cast<const uint8_t *>(d1) + off * stride,
+                                   static_cast<const uint8_t *>(d2) + off * stride,
+                                   static_cast<int32_t *>(d_out) + off, m, rows, gap, packed, st));
+    }
+    return SWMI_OK;
+}
+
+// Host-resident batch: two slots, each with its own stream; chunk k+1's H2D copy overlaps chunk k's kernel.
+int score_host_batch(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
+                     bool packed, bool one_vs_many)
+{
+    std::lock_guard<std::mutex> lock(g_ctx.mu);
+    const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
+    const size_t chunk = n < kChunkPairs ? n : kChunkPairs;
+    SmRows rows;
+    const LaunchConfig cfg = make_config(sm, gap, &rows);
+    for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
+        const int rc = ensure_slot(g_ctx.slots[k], chunk);
+        if (rc != SWMI_OK) return rc;
+    }
+    if (one_vs_many)   // the single seq2 goes to the head of slot 0's seq2 buffer... of every slot in use
+        for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k)
+            HIP_TRY(hipMemcpyAsync(g_ctx.slots[k].d_seq2, s2, kSeq, hipMemcpyHostToDevice, g_ctx.slots[k].stream));
+    size_t idx = 0;
+    for (size_t off = 0; off < n; off += chunk, ++idx) {
+        Slot &s = g_ctx.slots[idx % kSlots];
+        const size_t m = n - off < chunk ? n - off : chunk;
+        HIP_TRY(hipMemcpyAsync(s.d_seq1, s1 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream));
+        if (!one_vs_many)
+            HIP_TRY(hipMemcpyAsync(s.d_seq2, s2 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream));
+        if (one_vs_many)
+            HIP_TRY(swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, s.stream));
+        else
+            HIP_TRY(swmi::launch_score(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, packed, s.stream));
+        HIP_TRY(hipMemcpyAsync(out + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    }
+    for (int k = 0; k < kSlots; ++k)
+        if (g_ctx.slots[k].stream) HIP_TRY(hipStreamSynchronize(g_ctx.slots[k].stream));
+    return SWMI_OK;
+}
+
+}  // namespace
+
+// ---- deferred queue ------------------------------------------------------------------------------
+
+struct swmi_queue {
+    size_t max_pairs = 0, count = 0, shipped = 0;
+    size_t block = 1 << 16;             // pairs per asynchronous shipment
+    int8_t sm[16];
+    int gap = 0;
+    uint8_t *h_seq1 = nullptr, *h_seq2 = nullptr;   // pinned staging, max_pairs * 128 each
+    int32_t *h_scores = nullptr;                    // pinned results
+    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
+    int32_t *d_scores = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+int queue_ship(swmi_queue *q, size_t upto)
+{
+    if (upto <= q->shipped) return SWMI_OK;
+    const size_t off = q->shipped, m = upto - q->shipped;
+    HIP_TRY(hipMemcpyAsync(q->d_seq1 + off * kSeq, q->h_seq1 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->d_seq2 + off * kSeq, q->h_seq2 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
+    const int rc = launch_device(q->d_seq1 + off * kSeq, q->d_seq2 + off * kSeq, m, q->sm, q->gap, q->d_scores + off,
+                                 q->stream, false);
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(q->h_scores + off, q->d_scores + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, q->stream));
+    q->shipped = upto;
+    return SWMI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int swmi_version(void) { return SWMI_VERSION; }
+
+const char *swmi_last_error(void) { return t_error; }
+
+int swmi_init(int device)
+{
+    std::lock_guard<std::mutex> lock(g_init_mu);
+    t_error[0] = 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(SWMI_ERR_NO_DEVICE, "no HIP device available (%s); libswmi has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) % count : 0;
+    }
+    if (device >= count) return fail(SWMI_ERR_INVALID_ARGUMENT, "device %d out of range (count %d)", device, count);
+    if (g_ctx.ready) {
+        if (g_ctx.device == device) return SWMI_OK;
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "already initialised on device %d (one process per GPU); call swmi_shutdown() first",
+                    g_ctx.device);
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDeviceProperties(&g_ctx.prop, device));
+    if (strncmp(g_ctx.prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SWMI_ERR_UNSUPPORTED_ARCH, "device %d is %s; libswmi carries gfx950 (MI355X) code objects only", device,
+                    g_ctx.prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    for (auto &s : g_ctx.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    g_ctx.device = device;
+    const char *env_l = getenv("SWMI_LANES");
+    if (env_l && swmi::schedule_supported(atoi(env_l))) g_ctx.lanes = atoi(env_l);
+    g_ctx.ready = true;
+    return SWMI_OK;
+}
+
+int swmi_shutdown(void)
+{
+    std::lock_guard<std::mutex> lock(g_init_mu);
+    if (!g_ctx.ready) return SWMI_OK;
+    (void)hipSetDevice(g_ctx.device);
+    (void)hipDeviceSynchronize();
+    for (auto &s : g_ctx.slots) {
+        if (s.d_seq1) (void)hipFree(s.d_seq1);
+        if (s.d_seq2) (void)hipFree(s.d_seq2);
+        if (s.d_scores) (void)hipFree(s.d_scores);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s = Slot{};
+    }
+    if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.stream = nullptr;
+    g_ctx.ready = false;
+    g_ctx.device = -1;
+    return SWMI_OK;
+}
+
+int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
+{
+    if (lanes_per_alignment == 0) lanes_per_alignment = 8;
+    if (!swmi::schedule_supported(lanes_per_alignment))
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
+    if (flags & ~3u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
+    g_ctx.lanes = lanes_per_alignment;
+    g_ctx.flags = flags;
+    return SWMI_OK;
+}
+
+int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags)
+{
+    if (lanes_per_alignment) *lanes_per_alignment = g_ctx.lanes;
+    if (flags) *flags = g_ctx.flags;
+    return SWMI_OK;
+}
+
+int swmi_get_device_info(swmi_device_info *info)
+{
+    if (!info) return fail(SWMI_ERR_INVALID_ARGUMENT, "info is NULL");
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    memset(info, 0, sizeof *info);
+    info->device = g_ctx.device;
+    info->compute_units = g_ctx.prop.multiProcessorCount;
+    info->clock_khz = g_ctx.prop.clockRate;
+    info->wavefront_size = g_ctx.prop.warpSize;
+    info->hbm_bytes = g_ctx.prop.totalGlobalMem;
+    snprintf(info->arch, sizeof info->arch, "%s", g_ctx.prop.gcnArchName);
+    snprintf(info->name, sizeof info->name, "%s", g_ctx.prop.name);
+    return SWMI_OK;
+}
+
+int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, const int8_t score_matrix[16],
+                     int8_t gap_penalty, int32_t *scores)
+{
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (n == 0) return SWMI_OK;
+    if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    return score_host_batch(seq1s, seq2s, n, score_matrix, gap_penalty, scores, false, false);
+}
+
+int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq2[SWMI_SEQ_LEN], const int8_t score_matrix[16],
+                    int8_t gap_penalty)
+{
+    int32_t score = 0;
+    const int rc = swmi_score_batch(seq1, seq2, 1, score_matrix, gap_penalty, &score);
+    return rc == SWMI_OK ? score : rc;
+}
+
+int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t seq2[SWMI_SEQ_LEN],
+                           const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores)
+{
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (n_seq1 == 0) return SWMI_OK;
+    if (!seq1s || !seq2 || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seq1 = %zu", n_seq1);
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    return score_host_batch(seq1s, seq2, n_seq1, score_matrix, gap_penalty, scores, false, true);
+}
+
+int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_packed, size_t n,
+                            const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores)
+{
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (n == 0) return SWMI_OK;
+    if (!seq1s_packed || !seq2s_packed || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    return score_host_batch(seq1s_packed, seq2s_packed, n, score_matrix, gap_penalty, scores, true, false);
+}
+
+static int device_entry(const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out, void *stream,
+                        bool packed)
+{
+    int rc = check_params(sm, gap);
+    if (rc != SWMI_OK) return rc;
+    if (n == 0) return SWMI_OK;
+    if (!d1 || !d2 || !d_out) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    if ((reinterpret_cast<uintptr_t>(d1) | reinterpret_cast<uintptr_t>(d2) | reinterpret_cast<uintptr_t>(d_out)) & 15)
+        return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    return launch_device(d1, d2, n, sm, gap, d_out, st, packed);
+}
+
+int swmi_score_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, const int8_t score_matrix[16],
+                            int8_t gap_penalty, void *d_scores, void *stream)
+{
+    return device_entry(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, stream, false);
+}
+
+int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq2s_packed, size_t n,
+                                   const int8_t score_matrix[16], int8_t gap_penalty, void *d_scores, void *stream)
+{
+    return device_entry(d_seq1s_packed, d_seq2s_packed, n, score_matrix, gap_penalty, d_scores, stream, true);
+}
+
+int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
+{
+    if (n_seqs == 0) return SWMI_OK;
+    if (!packed || !unpacked) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seqs = %zu", n_seqs);
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    std::lock_guard<std::mutex> lock(g_ctx.mu);
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    // reuse slot 0: seq1 buffer holds the packed bytes, seq2 buffer the unpacked ones
+    const size_t chunk = n_seqs < kChunkPairs ? n_seqs : kChunkPairs;
+    rc = ensure_slot(g_ctx.slots[0], chunk);
+    if (rc != SWMI_OK) return rc;
+    Slot &s = g_ctx.slots[0];
+    for (size_t off = 0; off < n_seqs; off += chunk) {
+        const size_t m = n_seqs - off < chunk ? n_seqs - off : chunk;
+        HIP_TRY(hipMemcpyAsync(s.d_seq1, packed + off * SWMI_PACKED_LEN, m * SWMI_PACKED_LEN, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(swmi::launch_unpack(s.d_seq1, s.d_seq2, m, s.stream));
+        HIP_TRY(hipMemcpyAsync(unpacked + off * kSeq, s.d_seq2, m * kSeq, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
+    }
+    return SWMI_OK;
+}
+
+int swmi_generate_pairs_device(void *d_seq1s, void *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair, void *stream)
+{
+    if (n == 0) return SWMI_OK;
+    if (!d_seq1s || !d_seq2s) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2s)) & 15)
+        return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    HIP_TRY(swmi::launch_generate(static_cast<uint8_t *>(d_seq1s), static_cast<uint8_t *>(d_seq2s), n, seed, first_pair, st));
+    return SWMI_OK;
+}
+
+static uint64_t host_splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int swmi_generate_pairs_host(uint8_t *seq1s, uint8_t *seq2s, size_t n, uint64_t seed, uint64_t first_pair)
+{
+    if (n == 0) return SWMI_OK;
+    if (!seq1s || !seq2s) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    for (size_t k = 0; k < n; ++k)
+        for (uint64_t s = 0; s < 2; ++s) {
+            uint8_t *dst = (s ? seq2s : seq1s) + k * kSeq;
+            for (uint64_t w = 0; w < 4; ++w) {
+                const uint64_t ctr = ((first_pair + k) * 2 + s) * 4 + w;
+                const uint64_t x = host_splitmix64(seed ^ (ctr * 0x9E3779B97F4A7C15ull));
+                for (int b = 0; b < 32; ++b) dst[32 * w + b] = uint8_t((x >> (2 * b)) & 3);
+            }
+        }
+    return SWMI_OK;
+}
+
+int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, const int8_t score_matrix[16],
+                           int8_t gap_penalty, void *d_scores, void *stream, int iters, float *avg_ms)
+{
+    if (!avg_ms || iters <= 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "avg_ms is NULL or iters <= 0");
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int it = 0; it < iters; ++it) {
+        rc = device_entry(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, st, false);
+        if (rc != SWMI_OK) break;
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != SWMI_OK) return rc;
+    *avg_ms = ms / float(iters);
+    return SWMI_OK;
+}
+
+// ---- queue ---------------------------------------------------------------------------------------
+
+int swmi_queue_create(size_t max_pairs, const int8_t score_matrix[16], int8_t gap_penalty, swmi_queue **out)
+{
+    if (!out) return fail(SWMI_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (max_pairs == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "max_pairs is 0");
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    swmi_queue *q = new (std::nothrow) swmi_queue;
+    if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "out of host memory");
+    q->max_pairs = max_pairs;
+    memcpy(q->sm, score_matrix, 16);
+    q->gap = gap_penalty;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&q->h_seq1), max_pairs * kSeq, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&q->h_seq2), max_pairs * kSeq, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&q->h_scores), max_pairs * sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&q->d_seq1, max_pairs * kSeq);
+    if (e == hipSuccess) e = hipMalloc(&q->d_seq2, max_pairs * kSeq);
+    if (e == hipSuccess) e = hipMalloc(&q->d_scores, max_pairs * sizeof(int32_t));
+    if (e != hipSuccess) {
+        swmi_queue_destroy(q);
+        return fail(SWMI_ERR_HIP, "queue allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = q;
+    return SWMI_OK;
+}
+
+long long swmi_queue_submit(swmi_queue *q, const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq2[SWMI_SEQ_LEN])
+{
+    if (!q || !seq1 || !seq2) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (q->count >= q->max_pairs) return fail(SWMI_ERR_QUEUE_FULL, "queue holds %zu pairs (its capacity)", q->count);
+    const size_t k = q->count++;
+    memcpy(q->h_seq1 + k * kSeq, seq1, kSeq);
+    memcpy(q->h_seq2 + k * kSeq, seq2, kSeq);
+    if (q->count - q->shipped >= q->block) {
+        const int rc = queue_ship(q, q->count);
+        if (rc != SWMI_OK) return rc;
+    }
+    return (long long)k;
+}
+
+int swmi_queue_wait(swmi_queue *q, const int32_t **scores, size_t *n_scores)
+{
+    if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "queue is NULL");
+    int rc = queue_ship(q, q->count);
+    if (rc != SWMI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    if (scores) *scores = q->h_scores;
+    if (n_scores) *n_scores = q->count;
+    return SWMI_OK;
+}
+
+int swmi_queue_reset(swmi_queue *q)
+{
+    if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "queue is NULL");
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    q->count = q->shipped = 0;
+    return SWMI_OK;
+}
+
+int swmi_queue_destroy(swmi_queue *q)
+{
+    if (!q) return SWMI_OK;
+    if (q->stream) (void)hipStreamSynchronize(q->stream);
+    if (q->h_seq1) (void)hipHostFree(q->h_seq1);
+    if (q->h_seq2) (void)hipHostFree(q->h_seq2);
+    if (q->h_scores) (void)hipHostFree(q->h_scores);
+    if (q->d_seq1) (void)hipFree(q->d_seq1);
+    if (q->d_seq2) (void)hipFree(q->d_seq2);
+    if (q->d_scores) (void)hipFree(q->d_scores);
+    if (q->stream) (void)hipStreamDestroy(q->stream);
+    delete q;
+    return SWMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// swmi_internal.h -- declarations shared by the HIP kernels (sw_kernels.hip) and the C-ABI host side (swmi_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace swmi {
+
+// The 4x4 int8 score matrix as four dwords: rows.r[a] holds sm[a*4 + 0..3] in bytes 0..3
+// (index order of source.cpp:50: seq1 base selects the row, seq2 base the column).
+struct SmRows {
+    uint32_t r[4];
+};
+
+enum ScheduleFlags : unsigned {
+    kNoGapFold = 1u,   // never use the gap-folded recurrence
+    kUseI16 = 2u,      // compiler-scheduled 16-bit max variant (v_max_i16 is full rate, but see DESIGN.md section 5)
+};
+
+struct LaunchConfig {
+    int lanes_per_alignment;   // 64, 32, 16, 8, 4, 2
+    bool fold_gap;             // rows carry sm + gap (requires every sm + gap to fit int8)
+    bool use_i16;
+};
+
+// Score n pairs resident in device memory. packed = 2-bit inputs (32 B per sequence).
+hipError_t launch_score(const LaunchConfig &cfg, const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores,
+                        size_t n, const SmRows &rows, int gap, bool packed, hipStream_t stream);
+// Score n_seq1 sequences against one seq2 (device pointers; d_seq2 = 128 bytes).
+hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_seq1s, const uint8_t *d_seq2,
+                                    int32_t *d_scores, size_t n_seq1, const SmRows &rows, int gap, hipStream_t stream);
+hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,
+                           hipStream_t stream);
+hipError_t launch_unpack(const uint8_t *d_packed, uint8_t *d_unpacked, size_t n_seqs, hipStream_t stream);
+
+bool schedule_supported(int lanes_per_alignment);
+
+}  // namespace swmi

@@ -1,0 +1,243 @@
+"""ctypes binding of libswmi.so (include/swmi.h) -- the Python-side mirror used by tests/ and bench.py.
+
+The scoring entry points keep the reference's argument meaning (source.cpp:462-466):
+``score_pair(seq1, seq2, score_matrix, gap_penalty) -> int`` with 128-byte sequences, a 16-entry int8
+matrix indexed ``seq1_base * 4 + seq2_base`` and a non-negative gap penalty.  Nothing here computes
+scores on the CPU: every call goes through the C ABI into the gfx950 kernels and raises ``SwmiError``
+when the library or a usable device is missing.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+SEQ_LEN = 128
+PACKED_LEN = 32
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libswmi.so")
+
+OK = 0
+ERR_NOT_INITIALIZED = -1
+ERR_NO_DEVICE = -2
+ERR_UNSUPPORTED_ARCH = -3
+ERR_INVALID_ARGUMENT = -4
+ERR_DOMAIN = -5
+ERR_ALIGNMENT = -6
+ERR_HIP = -7
+ERR_QUEUE_FULL = -8
+
+NO_GAP_FOLD = 1
+USE_I16 = 2
+
+
+class SwmiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("swmi error %d: %s" % (code, message))
+        self.code = code
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("clock_khz", ctypes.c_int),
+                ("wavefront_size", ctypes.c_int), ("hbm_bytes", ctypes.c_size_t), ("arch", ctypes.c_char * 64),
+                ("name", ctypes.c_char * 128)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libswmi.so (built by smith-waterman-simd_amd/csrc/Makefile). Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SwmiError(ERR_NOT_INITIALIZED, "%s not built: run __graft_entry__.build() or make -C smith-waterman-simd_amd/csrc" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, u64, i8 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int8
+    lib.swmi_last_error.restype = ctypes.c_char_p
+    lib.swmi_init.argtypes = [ctypes.c_int]
+    lib.swmi_score_pair.argtypes = [vp, vp, vp, i8]
+    lib.swmi_score_batch.argtypes = [vp, vp, sz, vp, i8, vp]
+    lib.swmi_score_batch_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
+    lib.swmi_score_one_vs_many.argtypes = [vp, sz, vp, vp, i8, vp]
+    lib.swmi_score_batch_packed.argtypes = [vp, vp, sz, vp, i8, vp]
+    lib.swmi_score_batch_packed_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
+    lib.swmi_unpack.argtypes = [vp, sz, vp]
+    lib.swmi_queue_create.argtypes = [sz, vp, i8, ctypes.POINTER(vp)]
+    lib.swmi_queue_submit.argtypes = [vp, vp, vp]
+    lib.swmi_queue_submit.restype = ctypes.c_longlong
+    lib.swmi_queue_wait.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    lib.swmi_queue_reset.argtypes = [vp]
+    lib.swmi_queue_destroy.argtypes = [vp]
+    lib.swmi_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint]
+    lib.swmi_get_schedule.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)]
+    lib.swmi_generate_pairs_device.argtypes = [vp, vp, sz, u64, u64, vp]
+    lib.swmi_generate_pairs_host.argtypes = [vp, vp, sz, u64, u64]
+    lib.swmi_time_batch_device.argtypes = [vp, vp, sz, vp, i8, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    lib.swmi_get_device_info.argtypes = [ctypes.POINTER(DeviceInfo)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise SwmiError(rc, load().swmi_last_error().decode())
+    return rc
+
+
+def _u8(a, shape_last):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.shape[-1] != shape_last:
+        raise ValueError("last dimension must be %d" % shape_last)
+    return a
+
+
+def _sm(score_matrix):
+    sm = np.ascontiguousarray(score_matrix, dtype=np.int8).reshape(-1)
+    if sm.size != 16:
+        raise ValueError("score_matrix must have 16 entries")
+    return sm
+
+
+def match_matrix(match, mismatch):
+    """4x4 matrix with `match` on the diagonal and `mismatch` elsewhere (source.cpp:3041-3045)."""
+    sm = np.full((4, 4), mismatch, np.int8)
+    np.fill_diagonal(sm, match)
+    return sm.reshape(16)
+
+
+def init(device=-1):
+    _check(load().swmi_init(device))
+
+
+def shutdown():
+    _check(load().swmi_shutdown())
+
+
+def last_error():
+    return load().swmi_last_error().decode()
+
+
+def set_schedule(lanes_per_alignment=0, flags=0):
+    _check(load().swmi_set_schedule(lanes_per_alignment, flags))
+
+
+def get_schedule():
+    lanes, flags = ctypes.c_int(), ctypes.c_uint()
+    _check(load().swmi_get_schedule(ctypes.byref(lanes), ctypes.byref(flags)))
+    return lanes.value, flags.value
+
+
+def device_info():
+    info = DeviceInfo()
+    _check(load().swmi_get_device_info(ctypes.byref(info)))
+    return {"device": info.device, "compute_units": info.compute_units, "clock_khz": info.clock_khz,
+            "wavefront_size": info.wavefront_size, "hbm_bytes": info.hbm_bytes, "arch": info.arch.decode(),
+            "name": info.name.decode()}
+
+
+def score_pair(seq1, seq2, score_matrix, gap_penalty):
+    """Mirror of SmithWaterman_simd4(seq1, seq2, score_matrix, gap_penalty) (source.cpp:462-466)."""
+    a, b, sm = _u8(seq1, SEQ_LEN), _u8(seq2, SEQ_LEN), _sm(score_matrix)
+    return _check(load().swmi_score_pair(a.ctypes.data, b.ctypes.data, sm.ctypes.data, int(gap_penalty)))
+
+
+def score_batch(seq1s, seq2s, score_matrix, gap_penalty):
+    a, b, sm = _u8(seq1s, SEQ_LEN), _u8(seq2s, SEQ_LEN), _sm(score_matrix)
+    if a.shape != b.shape:
+        raise ValueError("seq1s and seq2s must have the same shape")
+    n = a.size // SEQ_LEN
+    out = np.zeros(n, np.int32)
+    _check(load().swmi_score_batch(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    return out
+
+
+def score_one_vs_many(seq1s, seq2, score_matrix, gap_penalty):
+    a, b, sm = _u8(seq1s, SEQ_LEN), _u8(seq2, SEQ_LEN), _sm(score_matrix)
+    n = a.size // SEQ_LEN
+    out = np.zeros(n, np.int32)
+    _check(load().swmi_score_one_vs_many(a.ctypes.data, n, b.ctypes.data, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    return out
+
+
+def score_batch_packed(seq1s_packed, seq2s_packed, score_matrix, gap_penalty):
+    a, b, sm = _u8(seq1s_packed, PACKED_LEN), _u8(seq2s_packed, PACKED_LEN), _sm(score_matrix)
+    n = a.size // PACKED_LEN
+    out = np.zeros(n, np.int32)
+    _check(load().swmi_score_batch_packed(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    return out
+
+
+def unpack(packed):
+    p = _u8(packed, PACKED_LEN)
+    n = p.size // PACKED_LEN
+    out = np.zeros((n, SEQ_LEN), np.uint8)
+    _check(load().swmi_unpack(p.ctypes.data, n, out.ctypes.data))
+    return out.reshape(p.shape[:-1] + (SEQ_LEN,))
+
+
+def pack(seqs):
+    """Host-side inverse of unpack() (source.cpp:1581): base k of byte i at bits 2k..2k+1."""
+    s = _u8(seqs, SEQ_LEN).reshape(-1, 32, 4) & 3
+    return (s[..., 0] | (s[..., 1] << 2) | (s[..., 2] << 4) | (s[..., 3] << 6)).astype(np.uint8).reshape(seqs.shape[:-1] + (32,))
+
+
+def score_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, stream=0, packed=False):
+    """Device pointers (ints). Asynchronous on `stream` (a hipStream_t value, 0 = library stream)."""
+    sm = _sm(score_matrix)
+    fn = load().swmi_score_batch_packed_device if packed else load().swmi_score_batch_device
+    _check(fn(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream))
+
+
+def generate_pairs_device(d_seq1s, d_seq2s, n, seed, first_pair=0, stream=0):
+    _check(load().swmi_generate_pairs_device(d_seq1s, d_seq2s, n, seed, first_pair, stream))
+
+
+def generate_pairs_host(n, seed, first_pair=0):
+    a = np.zeros((n, SEQ_LEN), np.uint8)
+    b = np.zeros((n, SEQ_LEN), np.uint8)
+    _check(load().swmi_generate_pairs_host(a.ctypes.data, b.ctypes.data, n, seed, first_pair))
+    return a, b
+
+
+def time_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, stream=0, iters=10):
+    sm = _sm(score_matrix)
+    ms = ctypes.c_float()
+    _check(load().swmi_time_batch_device(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream, iters,
+                                         ctypes.byref(ms)))
+    return ms.value
+
+
+class Queue:
+    """Deferred queue behind the per-pair signature (swmi_queue_* in include/swmi.h)."""
+
+    def __init__(self, max_pairs, score_matrix, gap_penalty):
+        self._q = ctypes.c_void_p()
+        sm = _sm(score_matrix)
+        _check(load().swmi_queue_create(max_pairs, sm.ctypes.data, int(gap_penalty), ctypes.byref(self._q)))
+
+    def submit(self, seq1, seq2):
+        a, b = _u8(seq1, SEQ_LEN), _u8(seq2, SEQ_LEN)
+        return _check(load().swmi_queue_submit(self._q, a.ctypes.data, b.ctypes.data))
+
+    def wait(self):
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(load().swmi_queue_wait(self._q, ctypes.byref(ptr), ctypes.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int32)), shape=(n.value,)).copy()
+
+    def reset(self):
+        _check(load().swmi_queue_reset(self._q))
+
+    def close(self):
+        if self._q:
+            load().swmi_queue_destroy(self._q)
+            self._q = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
