@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- alignments/s of the fixed-shape Smith-Waterman scorer on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--lanes L]
+
+A "step" is one pass of the hot path over one batch of synthetic pairs: every rank scores its own P pairs
+(P = 1,048,576 by default = BASELINE.json configs[1], "1M same-shape pairs on 1 MI355X") that are already
+resident in HBM when the timed region starts, and -- for N > 1 -- the int32 scores are all-gathered over
+RCCL (the path's only exchange step).  Weak scaling: per-GPU work is fixed as N grows.
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU); started plainly with --gpus N > 1 the script spawns that launcher as a child process.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sw128_kernel), measured live with HIP
+events on the launch stream inside the timed region; `cpu_baseline` (N = 1 only) is the reference's own simd4
+(oracle/_ref/libswref.so, compiled from the reference sources in the build container) timed on ONE host core
+of this box on a bounded sample of the same generated pairs, which doubles as a bit-exactness check of the GPU
+scores.  The oracle / reference build are used here only as checker and baseline, never as the measured path.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "smith-waterman-simd_amd")
+sys.path.insert(0, PKG)
+
+CELLS = 128 * 128
+INT_OPS_PER_ALIGNMENT = CELLS * 7          # 1 add, 2 sub, 4 max per cell (source.cpp:49-53)
+BYTES_PER_ALIGNMENT = 128 + 128 + 4
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate 32-bit integer lane-ops/s
+# (v_add_u32 / v_sub_u32 issue at 32 lanes/clk/SIMD; v_max_i32, v_max3_i32 and v_dot4 at half of that --
+#  tools/microbench/valu_rate*.hip).
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+HBM_PEAK_GBS = 8000.0
+REFERENCE_PUBLISHED_ALIGN_PER_S = 1e6 / 4.4    # README.md:4 of the reference: simd4 ~4.4 s / 1M on one EPYC 7501 core
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=1 << 20, help="pairs per GPU per step")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per alignment (0 = library default)")
+    ap.add_argument("--match", type=int, default=10)
+    ap.add_argument("--mismatch", type=int, default=-30)
+    ap.add_argument("--gap", type=int, default=15)
+    ap.add_argument("--seed", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto, ~10-15 s)")
+    return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(swmi, np, args, gpu_scores_head, sample):
+    """Reference simd4 (or, if the prebuilt reference is absent, the C oracle) on ONE host core."""
+    vp = ctypes.c_void_p
+    seq1, seq2 = swmi.generate_pairs_host(sample, args.seed, 0)
+    sm = swmi.match_matrix(args.match, args.mismatch)
+    out = np.zeros(sample, np.int32)
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
+    info = {}
+    if os.path.exists(ref_path):
+        ref = ctypes.CDLL(ref_path)
+        ref.swref_repeat.restype = ctypes.c_longlong
+        t0 = time.perf_counter()
+        ref.swref_batch(4, seq1.ctypes.data_as(vp), seq2.ctypes.data_as(vp), ctypes.c_size_t(sample),
+                        sm.ctypes.data_as(vp), args.gap, out.ctypes.data_as(vp))
+        dt = time.perf_counter() - t0
+        # the reference's own harness shape: ONE pair, 1,000,000 calls (source.cpp:3074-3082)
+        t1 = time.perf_counter()
+        ref.swref_repeat(4, seq1[0].ctypes.data_as(vp), seq2[0].ctypes.data_as(vp), sm.ctypes.data_as(vp), args.gap, 1000000)
+        rep_ms = (time.perf_counter() - t1) * 1e3
+        sys.stderr.write("simd4 version: %.0f ms / 1M\n" % rep_ms)      # line shape of source.cpp:3081
+        info = {"kind": "reference", "function": "SmithWaterman_simd4 (source.cpp:462-571), g++ -O3 -mavx2",
+                "repeat_one_pair_ms_per_1M": round(rep_ms, 1)}
+    else:
+        orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        t0 = time.perf_counter()
+        orc.sw_oracle_batch_st(seq1.ctypes.data_as(vp), seq2.ctypes.data_as(vp), ctypes.c_size_t(sample),
+                               sm.ctypes.data_as(vp), args.gap, out.ctypes.data_as(vp))
+        dt = time.perf_counter() - t0
+        info = {"kind": "port", "function": "oracle/sw_oracle.c scalar restatement of source.cpp:35-60"}
+    mism = int((out != gpu_scores_head[:sample]).sum())
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    info.update({"value": round(sample / dt, 1), "unit": "alignments/s", "cores": 1,
+                 "sample": "%d distinct generated pairs (seed %d, pairs 0..%d), same parameters" % (sample, args.seed, sample - 1),
+                 "seconds": round(dt, 2), "host_cpu": model, "host_cores_available": os.cpu_count(),
+                 "gpu_scores_checked": sample, "gpu_mismatches": mism})
+    return info
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return respawn_under_torchrun(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import swmi
+    from swmi import sharding
+
+    torch.cuda.set_device(local_rank)
+    swmi.init(local_rank)                       # raises if there is no gfx950 device: the bench never falls back
+    if args.lanes:
+        swmi.set_schedule(args.lanes, 0)
+    lanes, flags = swmi.get_schedule()
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P = args.pairs
+    n_total = P * world
+    lo, hi = sharding.shard_bounds(n_total, rank, world)        # contiguous shard of the global pair index space
+    dev = torch.device("cuda", local_rank)
+    d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+    d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    gathered = torch.empty(n_total, dtype=torch.int32, device=dev) if world > 1 else scores
+    stream = torch.cuda.current_stream()
+    swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
+    sm = swmi.match_matrix(args.match, args.mismatch)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, scores.data_ptr(), stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, scores)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps      # HIP events on the launch stream
+
+    # every rank must hold the same, complete score vector after the gather
+    checksum = int(gathered.to(torch.int64).sum().item())
+    if world > 1:
+        c = torch.tensor([checksum], dtype=torch.int64, device=dev)
+        cmin, cmax = c.clone(), c.clone()
+        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        assert int(cmin.item()) == int(cmax.item()), "ranks disagree on the gathered scores"
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        kernel_s = kernel_ms * 1e-3
+        roof = {
+            "bound": "valu",
+            "kernel": "sw128_kernel<L=%d>" % lanes,
+            "achieved": round(P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12, 3),
+            "peak": round(VALU_PEAK_TOPS, 1),
+            "unit": "TOP/s (int32)",
+            "frac": round(P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12 / VALU_PEAK_TOPS, 4),
+            "traffic": None,
+            "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_ops_per_launch": P * INT_OPS_PER_ALIGNMENT,
+            "algorithmic_bytes_per_launch": P * BYTES_PER_ALIGNMENT,
+            "hbm": {"achieved": round(P * BYTES_PER_ALIGNMENT / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(P * BYTES_PER_ALIGNMENT / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
+            "gcups_kernel": round(P * CELLS / kernel_s / 1e9, 1),
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("pairs_per_launch") == P:
+                    roof["traffic"] = tr.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+        line = {
+            "metric": "alignments/sec (and GCUPS) on 1M fixed-length pairs, 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
+            "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
+            "dtype": "int32", "data": "synthetic",
+            "gcups": round(value * CELLS / 1e9, 1),
+            "config": {"workload": "BASELINE.json configs[1]: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, "
+                                   "inputs resident in HBM, int32 scores%s" % (
+                                       P, args.match, args.mismatch, args.gap,
+                                       ", RCCL all-gather of scores each step" if world > 1 else ""),
+                       "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
+                       "parallelism": "batch-sharded x%d" % world},
+            "roofline": roof, "checksum": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or min(P, 1 << 20)
+            line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores.cpu().numpy(), min(sample, P))
+            line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -92,7 +92,7 @@ SWMI_API int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t
                               const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
 
 /* Same contract with all three buffers already resident in device memory (16-byte aligned
- * device pointers; `stream` is a hipStream_t or NULL for the library's own stream).
+ * device pointers; `stream` is a hipStream_t, NULL meaning the HIP null stream as usual).
  * Asynchronous: returns after the launch; the caller synchronises the stream.  This is the
  * entry bench.py times (inputs resident in HBM). */
 SWMI_API int swmi_score_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n,
@@ -151,7 +151,7 @@ SWMI_API int swmi_generate_pairs_host(uint8_t *seq1s, uint8_t *seq2s, size_t n, 
                                       uint64_t first_pair);
 
 /* ---- measurement ----------------------------------------------------------------------
- * Launches the batch kernel `iters` times back to back on `stream` (or the library stream)
+ * Launches the batch kernel `iters` times back to back on `stream` (NULL = the null stream)
  * bracketed by hipEvents on that same stream and returns the average per-launch duration. */
 SWMI_API int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n,
                                     const int8_t score_matrix[16], int8_t gap_penalty,

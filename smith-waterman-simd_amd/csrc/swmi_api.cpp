@@ -54,7 +54,7 @@ struct Context {
     bool ready = false;
     int device = -1;
     hipDeviceProp_t prop{};
-    hipStream_t stream = nullptr;       // library stream for *_device entry points called with stream == NULL
+    hipStream_t stream = nullptr;       // library-owned stream (host-side helpers)
     Slot slots[kSlots];
     int lanes = 8;                      // default schedule
     unsigned flags = 0;
@@ -351,7 +351,7 @@ static int device_entry(const void *d1, const void *d2, size_t n, const int8_t *
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
     rc = check_ready();
     if (rc != SWMI_OK) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     return launch_device(d1, d2, n, sm, gap, d_out, st, packed);
 }
 
@@ -398,7 +398,7 @@ int swmi_generate_pairs_device(void *d_seq1s, void *d_seq2s, size_t n, uint64_t 
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
     int rc = check_ready();
     if (rc != SWMI_OK) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     HIP_TRY(swmi::launch_generate(static_cast<uint8_t *>(d_seq1s), static_cast<uint8_t *>(d_seq2s), n, seed, first_pair, st));
     return SWMI_OK;
 }
@@ -433,7 +433,7 @@ int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, c
     if (!avg_ms || iters <= 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "avg_ms is NULL or iters <= 0");
     int rc = check_ready();
     if (rc != SWMI_OK) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : g_ctx.stream;
+    hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));

@@ -184,7 +184,7 @@ def pack(seqs):
 
 
 def score_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, stream=0, packed=False):
-    """Device pointers (ints). Asynchronous on `stream` (a hipStream_t value, 0 = library stream)."""
+    """Device pointers (ints). Asynchronous on `stream` (a hipStream_t value, 0 = the HIP null stream)."""
     sm = _sm(score_matrix)
     fn = load().swmi_score_batch_packed_device if packed else load().swmi_score_batch_device
     _check(fn(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream))

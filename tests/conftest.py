@@ -1,0 +1,110 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "smith-waterman-simd_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    need = [os.path.join(PKG, "lib", "libswmi.so"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+_ensure_built()
+
+
+class Oracle:
+    """ctypes view of oracle/liboracle.so -- the CPU checker (test infrastructure only)."""
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        self.lib.sw_oracle_score.restype = ctypes.c_int
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def score(self, seq1, seq2, sm, gap):
+        a = np.ascontiguousarray(seq1, np.uint8)
+        b = np.ascontiguousarray(seq2, np.uint8)
+        m = np.ascontiguousarray(sm, np.int8)
+        return self.lib.sw_oracle_score(self._p(a), self._p(b), self._p(m), int(gap))
+
+    def batch(self, seq1s, seq2s, sm, gap):
+        a = np.ascontiguousarray(seq1s, np.uint8)
+        b = np.ascontiguousarray(seq2s, np.uint8)
+        m = np.ascontiguousarray(sm, np.int8)
+        n = a.size // 128
+        out = np.zeros(n, np.int32)
+        self.lib.sw_oracle_batch(self._p(a), self._p(b), ctypes.c_size_t(n), self._p(m), int(gap), self._p(out))
+        return out
+
+    def generate(self, n, seed, first_pair=0):
+        a = np.zeros((n, 128), np.uint8)
+        b = np.zeros((n, 128), np.uint8)
+        self.lib.sw_oracle_generate(self._p(a), self._p(b), ctypes.c_size_t(n), ctypes.c_uint64(seed), ctypes.c_uint64(first_pair))
+        return a, b
+
+    def unpack(self, packed):
+        p = np.ascontiguousarray(packed, np.uint8).reshape(-1, 32)
+        out = np.zeros((p.shape[0], 128), np.uint8)
+        for k in range(p.shape[0]):
+            self.lib.sw_oracle_unpack(self._p(p[k]), self._p(out[k]))
+        return out
+
+    def pack(self, seqs):
+        s = np.ascontiguousarray(seqs, np.uint8).reshape(-1, 128)
+        out = np.zeros((s.shape[0], 32), np.uint8)
+        for k in range(s.shape[0]):
+            self.lib.sw_oracle_pack(self._p(s[k]), self._p(out[k]))
+        return out
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def swmi_mod():
+    import swmi
+    swmi.load()
+    return swmi
+
+
+@pytest.fixture(scope="session")
+def gpu(swmi_mod):
+    """Initialised library on device 0. Fails (never skips) when the HIP path is unavailable."""
+    swmi_mod.init(0)
+    swmi_mod.set_schedule(0, 0)
+    yield swmi_mod
+    swmi_mod.set_schedule(0, 0)
+
+
+def match_matrix(match, mismatch):
+    sm = np.full((4, 4), mismatch, np.int8)
+    np.fill_diagonal(sm, match)
+    return sm.reshape(16)

@@ -1,0 +1,89 @@
+"""The C ABI without a GPU: the library loads, exports every symbol include/swmi.h declares, and refuses to
+score when there is no device (there is no CPU fallback in the product path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, match_matrix
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "swmi.h")).read()
+    return sorted(set(re.findall(r"SWMI_API\s+[^;(]*?\b(swmi_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = _declared_symbols()
+    for must in ("swmi_init", "swmi_shutdown", "swmi_last_error", "swmi_score_pair", "swmi_score_batch",
+                 "swmi_score_batch_device", "swmi_score_one_vs_many", "swmi_score_batch_packed", "swmi_unpack",
+                 "swmi_queue_create", "swmi_queue_submit", "swmi_queue_wait", "swmi_queue_destroy",
+                 "swmi_set_schedule", "swmi_generate_pairs_device", "swmi_generate_pairs_host",
+                 "swmi_time_batch_device", "swmi_get_device_info"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(os.path.join(PKG, "lib", "libswmi.so"))
+    for name in _declared_symbols():
+        assert hasattr(lib, name), "libswmi.so does not export %s" % name
+    assert lib.swmi_version() == 100
+
+
+def test_product_library_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(PKG, "lib", "libswmi.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out and "swref" not in out
+    syms = subprocess.run(["nm", "-D", os.path.join(PKG, "lib", "libswmi.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "sw_oracle" not in syms and "swref_" not in syms
+
+
+def test_argument_errors_do_not_need_a_device(swmi_mod):
+    lib = swmi_mod.load()
+    sm = match_matrix(10, -30)
+    a = np.zeros(128, np.uint8)
+    out = np.zeros(1, np.int32)
+    vp = ctypes.c_void_p
+    # NULL matrix
+    assert lib.swmi_score_batch(a.ctypes.data, a.ctypes.data, 1, None, 15, out.ctypes.data) == swmi_mod.ERR_INVALID_ARGUMENT
+    # negative gap is outside the domain
+    assert lib.swmi_score_batch(a.ctypes.data, a.ctypes.data, 1, sm.ctypes.data, -1, out.ctypes.data) == swmi_mod.ERR_DOMAIN
+    assert b"gap_penalty" in lib.swmi_last_error()
+    # n = 0 is a no-op that needs neither buffers nor a device (the reference loop simply would not run)
+    assert lib.swmi_score_batch(None, None, 0, sm.ctypes.data, 15, None) == swmi_mod.OK
+    # NULL buffers with n > 0
+    assert lib.swmi_score_batch(None, a.ctypes.data, 1, sm.ctypes.data, 15, out.ctypes.data) == swmi_mod.ERR_INVALID_ARGUMENT
+    assert lib.swmi_set_schedule(3, 0) == swmi_mod.ERR_INVALID_ARGUMENT
+    assert lib.swmi_set_schedule(8, 0) == swmi_mod.OK
+
+
+def test_scoring_without_a_device_fails_loudly(swmi_mod):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the no-device behaviour is covered on the CPU runner")
+    lib = swmi_mod.load()
+    rc = lib.swmi_init(0)
+    assert rc == swmi_mod.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.swmi_last_error()
+    with pytest.raises(swmi_mod.SwmiError) as e:
+        swmi_mod.score_pair(np.zeros(128, np.uint8), np.zeros(128, np.uint8), match_matrix(1, -1), 1)
+    assert e.value.code == swmi_mod.ERR_NOT_INITIALIZED
+
+
+def test_host_generator_matches_the_oracle_generator(swmi_mod, oracle):
+    # two independent implementations of the specification in include/swmi.h
+    for seed, first in ((10000, 0), (1, 12345678901), (2**63 + 5, 2**40)):
+        a, b = swmi_mod.generate_pairs_host(257, seed, first)
+        oa, ob = oracle.generate(257, seed, first)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob)
+    a, _ = swmi_mod.generate_pairs_host(2, 10000, 0)
+    assert list(a[0][:16]) == [0, 3, 3, 1, 2, 0, 2, 3, 0, 1, 1, 2, 3, 0, 1, 2]   # known answer, pins the spec
+    a2, _ = swmi_mod.generate_pairs_host(1, 10000, 1)
+    assert np.array_equal(a2[0], a[1])                                           # counter-based: position independent
+
+
+def test_pack_helper_round_trips(swmi_mod, golden):
+    f = golden("f5_siblings")
+    assert np.array_equal(swmi_mod.pack(f["unpacked"]), f["packed"])

@@ -1,0 +1,114 @@
+"""Every entry point of include/swmi.h on the GPU: per-pair, queue, one-vs-many, packed, unpack,
+device-pointer batch, generator, timing helper, error paths."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import match_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_is_gfx950_and_native_library_is_loaded(gpu):
+    info = gpu.device_info()
+    assert info["arch"].startswith("gfx950") and info["wavefront_size"] == 64 and info["compute_units"] == 256
+    maps = open("/proc/self/maps").read()
+    assert "libswmi.so" in maps
+
+
+def test_per_pair_signature(gpu, oracle, golden):
+    f = golden("f3_harness")
+    sm = match_matrix(10, -30)
+    # the SpeedTest pair (source.cpp:3033-3046) scores 80, and 18 with the speedtest111x32 parameters
+    assert gpu.score_pair(f["seq1"][0], f["seq2"][0], sm, 15) == 80
+    assert gpu.score_pair(f["seq1"][0], f["seq2"][0], match_matrix(1, -1), 1) == 18
+    for k in range(1, 40):
+        assert gpu.score_pair(f["seq1"][k], f["seq2"][k], sm, 15) == int(f["scores"][0][k])
+
+
+def test_queue_behind_the_per_pair_signature(gpu, oracle):
+    n = 150001                      # several asynchronous shipments plus a ragged remainder
+    a, b = oracle.generate(n, 31337, 0)
+    sm = match_matrix(10, -30)
+    q = gpu.Queue(n, sm, 15)
+    lib = gpu.load()
+    # submit through the raw ABI to keep the loop fast
+    for k in range(n):
+        t = lib.swmi_queue_submit(q._q, a[k].ctypes.data, b[k].ctypes.data)
+        assert t == k
+    got = q.wait()
+    assert np.array_equal(got, oracle.batch(a, b, sm, 15))
+    with pytest.raises(gpu.SwmiError) as e:
+        q.submit(a[0], b[0])
+    assert e.value.code == gpu.ERR_QUEUE_FULL
+    q.reset()
+    assert q.submit(a[5], b[5]) == 0
+    assert list(q.wait()) == [oracle.score(a[5], b[5], sm, 15)]
+    q.close()
+
+
+def test_one_vs_many(gpu, oracle, golden):
+    f = golden("f5_siblings")       # SmithWaterman_8b111x32mark1/2/3, source.cpp:1227-1522: 32 seq1 x one seq2
+    sm = match_matrix(1, -1)
+    for blk in range(f["scores_111x32"].shape[0]):
+        got = gpu.score_one_vs_many(f["seq1"][32 * blk:32 * blk + 32], f["seq2"][blk], sm, 1)
+        assert np.array_equal(got, f["scores_111x32"][blk])
+    a, b = oracle.generate(5000, 3, 0)
+    sm2 = match_matrix(5, -4)
+    want = oracle.batch(a, np.repeat(b[:1], 5000, axis=0), sm2, 2)
+    assert np.array_equal(gpu.score_one_vs_many(a, b[0], sm2, 2), want)
+
+
+def test_fixed_111_scorer_is_the_general_one(gpu, golden):
+    f = golden("f5_siblings")       # SmithWaterman_111 / _8bit111simd, source.cpp:1073-1225
+    assert np.array_equal(gpu.score_batch(f["seq1"], f["seq2"], match_matrix(1, -1), 1), f["scores_111"])
+
+
+def test_unpack_and_packed_scoring(gpu, oracle, golden):
+    f = golden("f5_siblings")       # unpack(), source.cpp:1580-1583
+    assert np.array_equal(gpu.unpack(f["packed"]), f["unpacked"])
+    a, b = oracle.generate(10007, 99, 0)
+    pa, pb = oracle.pack(a), oracle.pack(b)
+    sm = match_matrix(10, -30)
+    want = oracle.batch(a, b, sm, 15)
+    for lanes in (64, 32, 16, 8, 4, 2):
+        gpu.set_schedule(lanes, 0)
+        try:
+            assert np.array_equal(gpu.score_batch_packed(pa, pb, sm, 15), want), lanes
+        finally:
+            gpu.set_schedule(0, 0)
+
+
+def test_device_pointer_batch_and_generator(gpu, oracle):
+    n = 20000
+    d1 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    d2 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    gpu.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, 10000, 123456789, st)
+    sm = match_matrix(10, -30)
+    gpu.score_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, 15, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    a, b = oracle.generate(n, 10000, 123456789)
+    assert np.array_equal(d1.cpu().numpy().reshape(n, 128), a)
+    assert np.array_equal(d2.cpu().numpy().reshape(n, 128), b)
+    assert np.array_equal(out.cpu().numpy(), oracle.batch(a, b, sm, 15))
+    ms = gpu.time_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, 15, out.data_ptr(), st, iters=3)
+    assert 0 < ms < 1000
+
+
+def test_error_paths_on_device(gpu):
+    sm = match_matrix(1, -1)
+    d = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    o = torch.empty(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(gpu.SwmiError) as e:
+        gpu.score_batch_device(d.data_ptr() + 1, d.data_ptr(), 4, sm, 1, o.data_ptr())
+    assert e.value.code == gpu.ERR_ALIGNMENT
+    with pytest.raises(gpu.SwmiError) as e:
+        gpu.score_batch(np.zeros((1, 128), np.uint8), np.zeros((1, 128), np.uint8), sm, -3)
+    assert e.value.code == gpu.ERR_DOMAIN
+    with pytest.raises(gpu.SwmiError) as e:
+        gpu.set_schedule(5, 0)
+    assert e.value.code == gpu.ERR_INVALID_ARGUMENT

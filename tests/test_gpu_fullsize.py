@@ -1,0 +1,94 @@
+"""BASELINE.json's full sizes (1M pairs = configs[1]) on the GPU: the whole batch against the multi-threaded
+CPU oracle, plus size-independent properties of the recurrence that need no oracle at all."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import match_matrix
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def resident(gpu):
+    d1 = torch.empty(N * 128, dtype=torch.uint8, device="cuda")
+    d2 = torch.empty(N * 128, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    gpu.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), N, 10000, 0, st)
+    torch.cuda.synchronize()
+    return d1, d2
+
+
+def _score(gpu, d1, d2, sm, gap, n=N):
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.score_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, gap, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_one_million_pairs_bit_exact_vs_oracle(gpu, oracle, resident):
+    d1, d2 = resident
+    sm = match_matrix(10, -30)      # SpeedTest parameters, source.cpp:3041-3046
+    got = _score(gpu, d1, d2, sm, 15).cpu().numpy()
+    a, b = oracle.generate(N, 10000, 0)
+    want = oracle.batch(a, b, sm, 15)          # OpenMP over the host cores
+    assert np.array_equal(got, want)
+    assert 30 <= got.min() and got.max() <= 400     # random DNA under (10,-30,15) clusters around 70-80
+    assert int(got.astype(np.int64).sum()) == 79139805   # checksum of this generated batch (bench.py prints the same)
+
+
+def test_all_schedules_agree_on_one_million_pairs(gpu, resident):
+    d1, d2 = resident
+    sm = match_matrix(1, -1)        # speedtest111x32 parameters, source.cpp:3202-3207
+    ref = None
+    try:
+        for lanes, flags in ((8, 0), (64, 0), (32, 1), (16, 2), (4, 3), (2, 0)):
+            gpu.set_schedule(lanes, flags)
+            s = _score(gpu, d1, d2, sm, 1)
+            if ref is None:
+                ref = s
+            assert torch.equal(s, ref), (lanes, flags)
+    finally:
+        gpu.set_schedule(0, 0)
+
+
+def test_symmetry_and_scaling_properties(gpu, resident):
+    d1, d2 = resident
+    rng = np.random.default_rng(2)
+    sm = rng.integers(-12, 13, 16).astype(np.int8)
+    smT = sm.reshape(4, 4).T.copy().reshape(16)
+    s_ab = _score(gpu, d1, d2, sm, 4)
+    s_ba = _score(gpu, d2, d1, smT, 4)          # swapping the sequences and transposing the matrix
+    assert torch.equal(s_ab, s_ba)
+    s_x3 = _score(gpu, d1, d2, (sm * 3).astype(np.int8), 12)   # the recurrence is homogeneous of degree 1
+    assert torch.equal(s_x3, s_ab * 3)
+    assert torch.equal(_score(gpu, d1, d2, sm, 4), s_ab)       # deterministic
+
+
+def test_self_alignment_and_position_independence(gpu, resident):
+    d1, _ = resident
+    sm = match_matrix(10, -30)
+    s = _score(gpu, d1, d1, sm, 15)
+    assert int(s.min()) == 1280 and int(s.max()) == 1280       # identical pair -> 128 * match
+    # a pair's score does not depend on where it sits in the batch (ragged offset into the resident buffer)
+    full = _score(gpu, resident[0], resident[1], sm, 15)
+    off = 12345
+    part = torch.empty(5000, dtype=torch.int32, device="cuda")
+    gpu.score_batch_device(resident[0].data_ptr() + off * 128, resident[1].data_ptr() + off * 128, 5000, sm, 15,
+                           part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(part, full[off:off + 5000])
+
+
+def test_monotone_in_gap_and_bounded(gpu, resident):
+    d1, d2 = resident
+    sm = match_matrix(5, -4)
+    prev = None
+    for gap in (0, 1, 3, 10, 127):
+        s = _score(gpu, d1, d2, sm, gap)
+        assert int(s.min()) >= 0 and int(s.max()) <= 128 * 5
+        if prev is not None:
+            assert bool((s <= prev).all())      # a larger gap penalty can never raise a score
+        prev = s

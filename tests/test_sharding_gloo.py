@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes run the sharding + final score gather of
+swmi/sharding.py, with the CPU oracle standing in for the GPU scorer (this test checks host logic only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT, Oracle, match_matrix
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    import sys
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from swmi import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = Oracle()
+    sm = match_matrix(10, -30)
+
+    def generate(first, n):
+        a, b = oracle.generate(n, 10000, first)
+        return torch.from_numpy(a), torch.from_numpy(b)
+
+    def score(a, b):
+        return torch.from_numpy(oracle.batch(a.numpy(), b.numpy(), sm, 15))
+
+    full = sharding.score_sharded(score, generate, n_total)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4096, 4097])
+def test_two_rank_shard_and_gather(tmp_path, oracle, n_total):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    a, b = oracle.generate(n_total, 10000, 0)
+    want = oracle.batch(a, b, match_matrix(10, -30), 15)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got, want), "rank %d" % r
+
+
+def test_shard_bounds_partition():
+    from swmi import sharding
+    for n in (0, 1, 7, 8, 1000003, 1 << 20):
+        for world in (1, 2, 3, 4, 8):
+            bounds = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            for (l0, h0), (l1, h1) in zip(bounds, bounds[1:]):
+                assert h0 == l1
+            sizes = [h - l for l, h in bounds]
+            assert max(sizes) - min(sizes) <= 1
