@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--gap", type=int, default=15)
     ap.add_argument("--seed", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
+                    "gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto, ~10-15 s)")
     return ap.parse_args()
 
@@ -117,6 +119,12 @@ def main():
     import swmi
     from swmi import sharding
 
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to measure)")
+    if args.backend == "nccl" and world > n_dev:
+        raise RuntimeError("%d ranks but %d GPUs: one process per GPU" % (world, n_dev))
+    local_rank %= n_dev                         # only differs from LOCAL_RANK in a gloo rehearsal on a smaller box
     torch.cuda.set_device(local_rank)
     swmi.init(local_rank)                       # raises if there is no gfx950 device: the bench never falls back
     if args.lanes:
@@ -124,7 +132,10 @@ def main():
     lanes, flags = swmi.get_schedule()
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     P = args.pairs
     n_total = P * world
@@ -132,31 +143,43 @@ def main():
     dev = torch.device("cuda", local_rank)
     d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
-    scores = torch.empty(P, dtype=torch.int32, device=dev)
-    gathered = torch.empty(n_total, dtype=torch.int32, device=dev) if world > 1 else scores
+    # two score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernel of step k+1
+    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else scores
+    pending = [None, None]
     stream = torch.cuda.current_stream()
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
     sm = swmi.match_matrix(args.match, args.mismatch)
 
-    def step(ev=None):
+    def step(k, ev=None):
+        buf = k % len(scores)
+        if pending[buf] is not None:
+            pending[buf].wait()                 # stream-side wait: the gather that read scores[buf] two steps ago is done
         if ev is not None:
             ev[0].record(stream)
-        swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, scores.data_ptr(), stream.cuda_stream)
+        swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, scores[buf].data_ptr(), stream.cuda_stream)
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, scores)
+            pending[buf] = dist.all_gather_into_tensor(gathered[buf], scores[buf], async_op=True)
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
+        step(k, events[k])
+    drain()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -167,7 +190,8 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps      # HIP events on the launch stream
 
     # every rank must hold the same, complete score vector after the gather
-    checksum = int(gathered.to(torch.int64).sum().item())
+    last = (args.steps - 1) % len(scores)
+    checksum = int(gathered[last].to(torch.int64).sum().item())
     if world > 1:
         c = torch.tensor([checksum], dtype=torch.int64, device=dev)
         cmin, cmax = c.clone(), c.clone()
@@ -213,14 +237,14 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, "
                                    "inputs resident in HBM, int32 scores%s" % (
                                        P, args.match, args.mismatch, args.gap,
-                                       ", RCCL all-gather of scores each step" if world > 1 else ""),
+                                       ", RCCL all-gather of scores each step (overlapped with the next step's kernel)" if world > 1 else ""),
                        "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
                        "parallelism": "batch-sharded x%d" % world},
             "roofline": roof, "checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or min(P, 1 << 20)
-            line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores.cpu().numpy(), min(sample, P))
+            line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores[0].cpu().numpy(), min(sample, P))
             line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:

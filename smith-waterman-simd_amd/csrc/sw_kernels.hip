@@ -28,6 +28,8 @@
 //             x = max(left, up, dot4c(row', onehot, diag)); h = sat_sub(x, gap); best tracks x
 #include "swmi_internal.h"
 
+#include <utility>
+
 namespace swmi {
 namespace {
 
@@ -224,10 +226,12 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
         int up = up_in;
         // Phase 1: every diagonal term of this column, t[i] = H(i-1, c-1) + s(i, c) (+ gap), from the OLD column
         // values (all still live, so the compiler picks the 3-address v_dot4_i32_i8 and needs no copies).
+        // clamp = true selects the 3-address VOP3P v_dot4_i32_i8 (the 2-address v_dot4c_i32_i8 would cost one
+        // v_mov per cell to preserve h[i-1]); the saturation can never trigger (|t| < 2^15).
         int tsum[R];
-        tsum[0] = __builtin_amdgcn_sdot4(row_scores[0], onehot, diag_in, false);
+        tsum[0] = __builtin_amdgcn_sdot4(row_scores[0], onehot, diag_in, true);
 #pragma unroll
-        for (int i = 1; i < R; ++i) tsum[i] = __builtin_amdgcn_sdot4(row_scores[i], onehot, h[i - 1], false);
+        for (int i = 1; i < R; ++i) tsum[i] = __builtin_amdgcn_sdot4(row_scores[i], onehot, h[i - 1], true);
         diag_in = up_in;
         // Phase 2: the top-to-bottom chain through `up`.
 #pragma unroll
@@ -260,6 +264,167 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
         best = best > other ? best : other;
     }
     if constexpr (FOLD) best = best > gap ? best - gap : 0;
+    if (j == 0 && live) scores[pair] = best;
+}
+
+
+// ---- LDS score fetch for the lookup variant ---------------------------------------------------------
+// ds_read_i8 returns the sign-extended byte, so the consumer is a plain full-rate v_add_u32.  (Left to itself hipcc
+// turns half of these into ds_read_u8 + v_add_u32_sdwa, a half-rate add.)  The loads are inline asm, so the compiler
+// does not count them: land_scores() is the matching wait -- one s_waitcnt, then an empty asm per register that makes
+// every consumer depend on it (cdna_hip_programming.md 5.7, form ii).
+template <int ROW>
+__device__ __forceinline__ void fetch_score(int &dst, uint32_t lds_addr)
+{
+    asm volatile("ds_read_i8 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(ROW * 256));
+}
+template <int R, int... I>
+__device__ __forceinline__ void fetch_scores_impl(int (&dst)[R], uint32_t lds_addr, std::integer_sequence<int, I...>)
+{
+    (fetch_score<I>(dst[I], lds_addr), ...);
+}
+template <int R>
+__device__ __forceinline__ void fetch_scores(int (&dst)[R], uint32_t lds_addr)
+{
+    fetch_scores_impl<R>(dst, lds_addr, std::make_integer_sequence<int, R>{});
+}
+template <int R>
+__device__ __forceinline__ void land_scores(int (&s)[R])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < R; ++i) asm volatile("" : "+v"(s[i]));
+}
+
+// ---- LDS-lookup variant ------------------------------------------------------------------------------
+//
+// Same recurrence (gap-folded body), but the score lookup leaves the VALU: every lane keeps the 4 int8 scores of each
+// of its rows in an LDS table, and ONE ds_read_i8 per cell -- address = lane slot + column base, row selected by the
+// instruction's immediate offset -- returns the sign-extended score.  The diagonal term is then a full-rate v_add_u32
+// instead of a half-rate v_dot4 (4 -> 2 issue cycles per cell); the LDS pipe is otherwise idle in this kernel.
+// Out-of-range columns (pipeline fill/drain) read a shared table of -128 bytes, which keeps not-yet-started rows at 0.
+// Scores for step t+1 are fetched while step t computes (two register sets, loop unrolled by two).
+template <int L, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+sw128_lut_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
+                 uint32_t n, SmRows rows, int gap)
+{
+    constexpr int R = kSeqLen / L;
+    constexpr int A = 64 / L;
+    constexpr int PAD = L + 4;              // the unrolled loop may run one step past T and prefetches two ahead
+    constexpr int S = kSeqLen + 2 * PAD;
+    constexpr int T2 = (kSeqLen + L - 1 + 1) / 2;   // pairs of steps
+    constexpr int NW = (R + 3) / 4;
+
+    __shared__ int lds_colofs[kWavesPerBlock][A * S];            // per column: byte offset into the lane's score slot
+    __shared__ uint32_t lds_q[kWavesPerBlock][R * 64];           // [row][lane] -> 4 x int8 scores (+ gap)
+    __shared__ uint32_t lds_neg[R * 64];                         // all bytes -128: what pad columns read
+    __shared__ uint32_t lds_rows[kWavesPerBlock][4];
+
+    for (int k = threadIdx.x; k < R * 64; k += 64 * kWavesPerBlock) lds_neg[k] = 0x80808080u;
+    __syncthreads();                        // before any wave may leave
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = lane / L;
+    const int j = lane % L;
+    const uint32_t first_pair = (blockIdx.x * kWavesPerBlock + wv) * A;
+    if (first_pair >= n) return;
+    uint32_t pair = first_pair + g;
+    const bool live = pair < n;
+    if (!live) pair = n - 1;
+
+    uint32_t a_w[NW], b_w[NW];
+    if constexpr (MODE == 1) {
+        if constexpr (R == 2) {
+            const uint32_t sh = 4 * (j & 1);
+            a_w[0] = spread4((seq1s[(size_t)pair * 32 + (j >> 1)] >> sh) & 0xf);
+            b_w[0] = spread4((seq2s[(size_t)pair * 32 + (j >> 1)] >> sh) & 0xf);
+        } else {
+            load_bases_packed<R>(seq1s + (size_t)pair * 32 + j * (R / 4), a_w);
+            load_bases_packed<R>(seq2s + (size_t)pair * 32 + j * (R / 4), b_w);
+        }
+    } else {
+        load_bases<R>(seq1s + (size_t)pair * kSeqLen + j * R, a_w);
+        load_bases<R>(seq2s + (MODE == 2 ? (size_t)0 : (size_t)pair * kSeqLen) + j * R, b_w);
+    }
+
+    if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
+    // byte distance from this wave's score table to the shared -128 table (same [row][lane] indexing)
+    const int neg_ofs = (int)((const char *)lds_neg - (const char *)lds_q[wv]);
+    int *prof = &lds_colofs[wv][g * S];
+    for (int k = j; k < PAD; k += L) {
+        prof[k] = neg_ofs;
+        prof[PAD + kSeqLen + k] = neg_ofs;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) prof[PAD + j * R + i] = (int)((b_w[i / 4] >> (8 * (i % 4))) & 3u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint32_t a = (a_w[i / 4] >> (8 * (i % 4))) & 3u;
+        lds_q[wv][i * 64 + lane] = lds_rows[wv][a];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // LDS byte address of this lane's slot in row 0 of the score table; + row * 256 (immediate) + column offset
+    const uint32_t qlane = (uint32_t)(uintptr_t)(&lds_q[wv][lane]);
+    const int *col = prof + PAD - j;
+
+    int h[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) h[i] = 0;
+    int best = 0;
+    int u0 = 0, u1 = 0;                     // alternating: value from lane j-1 for this step / the step before
+    const int group_mask = j == 0 ? 0 : -1;
+
+    int sA[R], sB[R];
+    fetch_scores<R>(sA, qlane + (uint32_t)col[0]);
+    int ofs_next = col[1];
+
+    auto step = [&](const int (&sc)[R], int up, int diag) {
+        int dprev = diag;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int left = h[i];
+            const int tsum = dprev + sc[i];
+            const int lu = left > up ? left : up;
+            const int x = lu > tsum ? lu : tsum;
+            best = best > x ? best : x;
+            const int hn = sat_sub<false>(x, gap);
+            h[i] = hn;
+            up = hn;
+            dprev = left;
+        }
+        return from_prev_lane<L>(up, group_mask);
+    };
+
+    for (int t2 = 0; t2 < T2; ++t2) {
+        {   // step 2*t2: scores in sA (fetched one step ago); start fetching sB for step 2*t2+1
+            land_scores<R>(sA);
+            fetch_scores<R>(sB, qlane + (uint32_t)ofs_next);
+            ofs_next = col[2 * t2 + 2];
+            u1 = step(sA, u0, u1);          // u1 now: from lane j-1 for step 2*t2+1; u0 is its diagonal
+        }
+        {   // step 2*t2+1
+            land_scores<R>(sB);
+            fetch_scores<R>(sA, qlane + (uint32_t)ofs_next);
+            ofs_next = col[2 * t2 + 3];
+            u0 = step(sB, u1, u0);
+        }
+    }
+    land_scores<R>(sA);                     // drain the last prefetch before the registers are reused
+
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+        const int other = __shfl_xor(best, o);
+        best = best > other ? best : other;
+    }
+    best = best > gap ? best - gap : 0;
     if (j == 0 && live) scores[pair] = best;
 }
 
@@ -319,6 +484,12 @@ hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s
     if (blocks > 0x7fffffffull || n > 0xffffffffull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
     const uint32_t n32 = (uint32_t)n;
+    if constexpr (L <= 16 && L >= 4) {
+        if (cfg.fold_gap && cfg.use_lut) {
+            hipLaunchKernelGGL((sw128_lut_kernel<L, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+            return hipGetLastError();
+        }
+    }
     if (cfg.fold_gap) {
         if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, true, true, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
         else             hipLaunchKernelGGL((sw128_kernel<L, true, false, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);

@@ -95,6 +95,7 @@ LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows)
     LaunchConfig cfg;
     cfg.lanes_per_alignment = g_ctx.lanes;
     cfg.use_i16 = (g_ctx.flags & swmi::kUseI16) != 0;
+    cfg.use_lut = (g_ctx.flags & swmi::kUseLut) != 0;
     bool fold = !(g_ctx.flags & swmi::kNoGapFold);
     for (int k = 0; k < 16 && fold; ++k) {
         const int v = int(sm[k]) + gap;
@@ -264,7 +265,7 @@ int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
     if (lanes_per_alignment == 0) lanes_per_alignment = 8;
     if (!swmi::schedule_supported(lanes_per_alignment))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
-    if (flags & ~3u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
+    if (flags & ~7u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
     g_ctx.lanes = lanes_per_alignment;
     g_ctx.flags = flags;
     return SWMI_OK;

@@ -14,6 +14,7 @@ struct SmRows {
 
 enum ScheduleFlags : unsigned {
     kNoGapFold = 1u,   // never use the gap-folded recurrence
+    kUseLut = 4u,      // LDS score-lookup kernel (sw128_lut_kernel)
     kUseI16 = 2u,      // compiler-scheduled 16-bit max variant (v_max_i16 is full rate, but see DESIGN.md section 5)
 };
 
@@ -21,6 +22,7 @@ struct LaunchConfig {
     int lanes_per_alignment;   // 64, 32, 16, 8, 4, 2
     bool fold_gap;             // rows carry sm + gap (requires every sm + gap to fit int8)
     bool use_i16;
+    bool use_lut;              // LDS score lookup instead of v_dot4 (gap-folded body only, L in {16, 8, 4})
 };
 
 // Score n pairs resident in device memory. packed = 2-bit inputs (32 B per sequence).

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (made by tools/profile_gpu.sh) into profiles/<tag>_*.{csv,json}.
+
+HBM traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B... the
+counters are reported in kilobytes; on gfx950 FETCH_SIZE reads exactly half of the bytes of a wide coalesced streaming
+read (128-B requests tallied at 64 B), so the read side is doubled; WRITE_SIZE is exact for streaming stores.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+KERNEL = "sw128_kernel"
+
+
+def counter_rows(sub):
+    rows = []
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def per_kernel_avg(rows):
+    acc = {}
+    for r in rows:
+        if KERNEL not in r.get("Kernel_Name", ""):
+            continue
+        name, val = r["Counter_Name"], float(r["Counter_Value"])
+        s, n = acc.get(name, (0.0, 0))
+        acc[name] = (s + val, n + 1)
+    return {k: s / n for k, (s, n) in acc.items()}
+
+
+summary = {"tag": tag}
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+    for r in csv.DictReader(open(f)):
+        if KERNEL in r["Name"]:
+            summary["kernel"] = r["Name"]
+            summary["calls"] = int(r["Calls"])
+            summary["avg_ns"] = float(r["AverageNs"])
+            summary["min_ns"] = float(r["MinNs"])
+for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    summary.update({k: round(v, 1) for k, v in per_kernel_avg(counter_rows(sub)).items()})
+if "SQ_BUSY_CYCLES" in summary and "SQ_ACTIVE_INST_VALU" in summary:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES per SE ... keep raw numbers, derive simple ratios
+    pass
+if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
+    fetch_b = summary.get("FETCH_SIZE", 0.0) * 1024.0
+    write_b = summary.get("WRITE_SIZE", 0.0) * 1024.0
+    summary["hbm_read_bytes_corrected"] = fetch_b * 2.0     # gfx950: FETCH_SIZE reports half of a wide coalesced read
+    summary["hbm_write_bytes"] = write_b
+    summary["hbm_bytes_per_launch"] = fetch_b * 2.0 + write_b
+json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True))
