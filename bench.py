@@ -42,8 +42,11 @@ REFERENCE_PUBLISHED_ALIGN_PER_S = 1e6 / 4.4    # README.md:4 of the reference: s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30, help="untimed steps (the clock takes ~10 launches to settle after idle)")
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many"],
+                    help="pairs = the headline path; packed = 2-bit inputs (SURVEY 8f N3); one-vs-many = every seq1 against "
+                         "ONE seq2 (N1) -- secondary rows, same kernel, same contract")
     ap.add_argument("--pairs", type=int, default=1 << 20, help="pairs per GPU per step")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per alignment (0 = library default)")
     ap.add_argument("--match", type=int, default=10)
@@ -143,6 +146,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+    p1 = p2 = None
     # two score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernel of step k+1
     scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else scores
@@ -150,6 +154,19 @@ def main():
     stream = torch.cuda.current_stream()
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
     sm = swmi.match_matrix(args.match, args.mismatch)
+    if args.mode == "packed":                   # pack on the device with torch (input preparation, outside the timed region)
+        def pack(d):
+            v = d.view(P, 32, 4).to(torch.int32)
+            return (v[..., 0] | (v[..., 1] << 2) | (v[..., 2] << 4) | (v[..., 3] << 6)).to(torch.uint8).contiguous()
+        p1, p2 = pack(d1), pack(d2)
+
+    def launch(out_ptr):
+        if args.mode == "packed":
+            swmi.score_batch_device(p1.data_ptr(), p2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream, packed=True)
+        elif args.mode == "one-vs-many":
+            swmi.score_one_vs_many_device(d1.data_ptr(), P, d2.data_ptr(), sm, args.gap, out_ptr, stream.cuda_stream)
+        else:
+            swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream)
 
     def step(k, ev=None):
         buf = k % len(scores)
@@ -157,7 +174,7 @@ def main():
             pending[buf].wait()                 # stream-side wait: the gather that read scores[buf] two steps ago is done
         if ev is not None:
             ev[0].record(stream)
-        swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, scores[buf].data_ptr(), stream.cuda_stream)
+        launch(scores[buf].data_ptr())
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
@@ -202,6 +219,7 @@ def main():
     if rank == 0:
         value = n_total * args.steps / elapsed
         kernel_s = kernel_ms * 1e-3
+        bytes_per_alignment = {"pairs": BYTES_PER_ALIGNMENT, "packed": 32 + 32 + 4, "one-vs-many": 128 + 4}[args.mode]
         roof = {
             "bound": "valu",
             "kernel": "sw128_kernel<L=%d>" % lanes,
@@ -212,16 +230,16 @@ def main():
             "traffic": None,
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_ops_per_launch": P * INT_OPS_PER_ALIGNMENT,
-            "algorithmic_bytes_per_launch": P * BYTES_PER_ALIGNMENT,
-            "hbm": {"achieved": round(P * BYTES_PER_ALIGNMENT / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(P * BYTES_PER_ALIGNMENT / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
+            "algorithmic_bytes_per_launch": P * bytes_per_alignment,
+            "hbm": {"achieved": round(P * bytes_per_alignment / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(P * bytes_per_alignment / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
             "gcups_kernel": round(P * CELLS / kernel_s / 1e9, 1),
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
-                if tr.get("pairs_per_launch") == P:
+                if tr.get("pairs_per_launch") == P and args.mode == "pairs":
                     roof["traffic"] = tr.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = tr.get("source")
             except Exception:
@@ -234,15 +252,17 @@ def main():
             "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
             "dtype": "int32", "data": "synthetic",
             "gcups": round(value * CELLS / 1e9, 1),
-            "config": {"workload": "BASELINE.json configs[1]: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, "
+            "config": {"workload": "%s: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, "
                                    "inputs resident in HBM, int32 scores%s" % (
+                                       {"pairs": "BASELINE.json configs[1]", "packed": "SURVEY 8f N3 (2-bit packed inputs, source.cpp:1581)",
+                                        "one-vs-many": "SURVEY 8f N1 (every seq1 vs ONE seq2, source.cpp:1227)"}[args.mode],
                                        P, args.match, args.mismatch, args.gap,
                                        ", RCCL all-gather of scores each step (overlapped with the next step's kernel)" if world > 1 else ""),
                        "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
                        "parallelism": "batch-sharded x%d" % world},
             "roofline": roof, "checksum": checksum,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "pairs":
             sample = args.cpu_sample or min(P, 1 << 20)
             line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores[0].cpu().numpy(), min(sample, P))
             line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -105,6 +105,11 @@ SWMI_API int swmi_score_batch_device(const void *d_seq1s, const void *d_seq2s, s
 SWMI_API int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t seq2[SWMI_SEQ_LEN],
                                     const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
 
+/* Same, device-resident (d_seq1s: n_seq1 x 128 bytes, d_seq2: 128 bytes, 16-byte aligned), asynchronous on `stream`. */
+SWMI_API int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void *d_seq2,
+                                           const int8_t score_matrix[16], int8_t gap_penalty,
+                                           void *d_scores, void *stream);
+
 /* 2-bit packed inputs in the reference's own wire format (unpack(), source.cpp:1580-1583:
  * base k of byte i = (src[i] >> 2k) & 3): pair k is the 32 bytes at seq1s_packed + 32*k.
  * The kernel unpacks on the fly (no unpacked copy in HBM).  Host buffers. */
@@ -135,8 +140,9 @@ SWMI_API int swmi_queue_destroy(swmi_queue *q);
  * The reference ships nine schedules of one semantics (simd .. simd9).  So does this
  * library: `lanes_per_alignment` L in {64,32,16,8,4,2} lanes of a 64-lane wavefront walk one
  * alignment's anti-diagonal (each lane owns 128/L consecutive rows); L = 64 is literally
- * "one wavefront per alignment".  0 selects the default (fastest measured).
- * flags: bit 0 = disable the gap-folded cell body; bit 1 = 16-bit-max cell body (both: same results). */
+ * "one wavefront per alignment".  0 selects the default (fastest measured, L = 4).
+ * flags (all give identical scores): bit 0 = never fold the gap into the matrix rows (general cell body);
+ * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only). */
 SWMI_API int swmi_set_schedule(int lanes_per_alignment, unsigned flags);
 SWMI_API int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags);
 

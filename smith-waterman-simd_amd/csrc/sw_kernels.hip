@@ -28,6 +28,7 @@
 //             x = max(left, up, dot4c(row', onehot, diag)); h = sat_sub(x, gap); best tracks x
 #include "swmi_internal.h"
 
+#include <type_traits>
 #include <utility>
 
 namespace swmi {
@@ -152,12 +153,18 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 {
     constexpr int R = kSeqLen / L;          // rows per lane
     constexpr int A = 64 / L;               // alignments per wavefront
-    constexpr int PAD = L < 4 ? 4 : L;      // zero profile entries either side of the 128 columns
+    constexpr int PAD = L + 2;              // zero profile entries either side (the 2-step loop may run one step past T
+                                            // and reads one entry ahead)
     constexpr int S = kSeqLen + 2 * PAD;    // profile entries per alignment
-    constexpr int T = kSeqLen + L - 1;      // anti-diagonal steps
+    constexpr int T2 = (kSeqLen + L) / 2;   // pairs of anti-diagonal steps: covers T = 128 + L - 1 steps (+1 harmless)
     constexpr int NW = (R + 3) / 4;
 
-    __shared__ uint32_t lds_profile[kWavesPerBlock][A * S];   // one-hot query profile (seq2), per wave
+    // One-hot query profile of seq2, per wave: the one-hot dword itself (1 << 8*base, 0 for a pad column).
+    // (A 16-bit encoding (1 << 8) | 8*base, decoded per step with two shifts, halves the LDS and lifts L = 4 from 4 to 5
+    // workgroups per CU -- measured slower: the kernel is issue bound from 3 waves per SIMD up, the two shifts are not free.)
+    constexpr bool kWideProfile = true;
+    using profile_t = std::conditional_t<kWideProfile, uint32_t, uint16_t>;
+    __shared__ profile_t lds_profile[kWavesPerBlock][A * S];
     __shared__ uint32_t lds_rows[kWavesPerBlock][4];          // score-matrix rows, per wave
 
     const int lane = threadIdx.x & 63;
@@ -188,7 +195,7 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 
     // ---- stage the score-matrix rows and the one-hot query profile in LDS ------------------------
     if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
-    uint32_t *prof = &lds_profile[wv][g * S];
+    profile_t *prof = &lds_profile[wv][g * S];
     for (int k = j; k < PAD; k += L) {
         prof[k] = 0;
         prof[PAD + kSeqLen + k] = 0;
@@ -196,7 +203,7 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const uint32_t b = (b_w[i / 4] >> (8 * (i % 4))) & 3u;
-        prof[PAD + j * R + i] = 1u << (8 * b);
+        prof[PAD + j * R + i] = kWideProfile ? (profile_t)(1u << (8u * b)) : (profile_t)(0x100u | (8u * b));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -209,52 +216,71 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
         row_scores[i] = (int)lds_rows[wv][a];
     }
 
-    // ---- anti-diagonal sweep ------------------------------------------------------------------------
+    // ---- anti-diagonal sweep, two steps per iteration ---------------------------------------------------
+    // Three cell bodies, identical scores:
+    //   FOLD            rows hold s + gap:  x = max3(left, up, dot4(row', onehot, diag)); h = x -sat gap; best tracks x
+    //   !FOLD, !I16     any int8 matrix:    h = max3(gleft, gup, dot4(row, onehot, diag)); g = h -sat gap  (g kept per row:
+    //                                       one more register per row, same 3.5 instructions per cell as FOLD)
+    //   !FOLD, I16      16-bit max form:    h = max(max(left, up) -sat gap, dot4(...)) on v_max_i16 (A/B only)
+    constexpr bool kKeepG = !FOLD && !I16;
     int h[R];                               // h[i] = H(row i, previous column)
+    int hg[kKeepG ? R : 1];                 // hg[i] = max(h[i] - gap, 0)
 #pragma unroll
     for (int i = 0; i < R; ++i) h[i] = 0;
-    int best = 0;
-    int up_in = 0;                          // H(last row of lane j-1, this column)
-    int diag_in = 0;                        // H(last row of lane j-1, previous column)
-    const int group_mask = j == 0 ? 0 : -1;
-    const uint32_t *col = prof + PAD - j;   // col[t] = profile entry of column t - j
-    uint32_t onehot_next = col[0];
-
-    for (int t = 0; t < T; ++t) {
-        const int onehot = (int)onehot_next;
-        onehot_next = col[t + 1];
-        int up = up_in;
-        // Phase 1: every diagonal term of this column, t[i] = H(i-1, c-1) + s(i, c) (+ gap), from the OLD column
-        // values (all still live, so the compiler picks the 3-address v_dot4_i32_i8 and needs no copies).
-        // clamp = true selects the 3-address VOP3P v_dot4_i32_i8 (the 2-address v_dot4c_i32_i8 would cost one
-        // v_mov per cell to preserve h[i-1]); the saturation can never trigger (|t| < 2^15).
-        int tsum[R];
-        tsum[0] = __builtin_amdgcn_sdot4(row_scores[0], onehot, diag_in, true);
 #pragma unroll
-        for (int i = 1; i < R; ++i) tsum[i] = __builtin_amdgcn_sdot4(row_scores[i], onehot, h[i - 1], true);
-        diag_in = up_in;
-        // Phase 2: the top-to-bottom chain through `up`.
+    for (int i = 0; i < (kKeepG ? R : 1); ++i) hg[i] = 0;
+    int best = 0;
+    int u0 = 0, u1 = 0;                     // H(last row of lane j-1): this step's column / the previous one, alternating
+    // opaque so that hipcc emits one v_and_b32_dpp per step instead of v_mov_b32_dpp + v_cndmask_b32
+    const int group_mask = keep(j == 0 ? 0 : -1);
+    const profile_t *col = prof + PAD - j;  // col[t] = profile entry of column t - j
+
+    // one anti-diagonal step: `up` = H(last row of lane j-1, this column), `diag` = same, previous column
+    auto step = [&](uint32_t entry, int up, int diag) {
+        const int onehot = kWideProfile ? (int)entry : (int)((entry >> 8) << (entry & 31u));
+        // Diagonal terms t[i] = H(i-1, c-1) + s(i, c) (+ gap): one v_dot4_i32_i8 each (lookup and add fused).
+        // clamp = true selects the 3-address VOP3P form (the 2-address v_dot4c_i32_i8 costs a v_mov per cell); the
+        // saturation can never trigger (|t| < 2^15).
+        int dprev = diag;
+        if constexpr (kKeepG) up = sat_sub<false>(up, gap);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
+            const int left = h[i];
+            const int tsum = __builtin_amdgcn_sdot4(row_scores[i], onehot, dprev, true);
             int hn;
             if constexpr (FOLD) {
-                const int lu = h[i] > up ? h[i] : up;
-                const int x = lu > tsum[i] ? lu : tsum[i];                  // v_max3_i32 (half rate, two maxes)
+                const int lu = left > up ? left : up;
+                const int x = lu > tsum ? lu : tsum;                        // v_max3_i32 (half rate, two maxes)
                 best = I16 ? keep(max_i16(best, x)) : vmax<false>(best, x);
                 hn = sat_sub<I16>(x, gap);
+                up = hn;
             } else if constexpr (I16) {
-                const int m = keep(max_i16(h[i], up));
-                hn = keep(max_i16(sat_sub<true>(m, gap), tsum[i]));
+                const int m = keep(max_i16(left, up));
+                hn = keep(max_i16(sat_sub<true>(m, gap), tsum));
                 best = keep(max_i16(best, hn));
+                up = hn;
             } else {
-                const int m = vmax<false>(h[i], up);
-                hn = vmax<false>(sat_sub<false>(m, gap), tsum[i]);
+                const int gl = hg[i];
+                const int lu = gl > up ? gl : up;
+                hn = lu > tsum ? lu : tsum;                                 // v_max3_i32; >= 0 because gl >= 0
                 best = vmax<false>(best, hn);
+                const int gn = sat_sub<false>(hn, gap);
+                hg[i] = gn;
+                up = gn;
             }
             h[i] = hn;
-            up = hn;
+            dprev = left;
         }
-        up_in = from_prev_lane<L>(up, group_mask);
+        return from_prev_lane<L>(h[R - 1], group_mask);
+    };
+
+    uint32_t e0 = col[0];
+    for (int t2 = 0; t2 < T2; ++t2) {
+        const uint32_t e1 = col[2 * t2 + 1];
+        const uint32_t e2 = col[2 * t2 + 2];
+        u1 = step(e0, u0, u1);              // u1: from lane j-1 for the next step; u0 becomes its diagonal
+        u0 = step(e1, u1, u0);
+        e0 = e2;
     }
 
     // ---- reduce over the L lanes of the group, one int32 per alignment ------------------------------
@@ -380,7 +406,7 @@ sw128_lut_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ 
     for (int i = 0; i < R; ++i) h[i] = 0;
     int best = 0;
     int u0 = 0, u1 = 0;                     // alternating: value from lane j-1 for this step / the step before
-    const int group_mask = j == 0 ? 0 : -1;
+    const int group_mask = keep(j == 0 ? 0 : -1);
 
     int sA[R], sB[R];
     fetch_scores<R>(sA, qlane + (uint32_t)col[0]);
@@ -486,16 +512,16 @@ hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s
     const uint32_t n32 = (uint32_t)n;
     if constexpr (L <= 16 && L >= 4) {
         if (cfg.fold_gap && cfg.use_lut) {
-            hipLaunchKernelGGL((sw128_lut_kernel<L, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+            hipLaunchKernelGGL((sw128_lut_kernel<L, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);
             return hipGetLastError();
         }
     }
     if (cfg.fold_gap) {
-        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, true, true, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
-        else             hipLaunchKernelGGL((sw128_kernel<L, true, false, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, true, true, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);
+        else             hipLaunchKernelGGL((sw128_kernel<L, true, false, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);
     } else {
-        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, false, true, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
-        else             hipLaunchKernelGGL((sw128_kernel<L, false, false, MODE>), grid, block, 0, stream, s1, s2, out, n32, rows, gap);
+        if (cfg.use_i16) hipLaunchKernelGGL((sw128_kernel<L, false, true, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);
+        else             hipLaunchKernelGGL((sw128_kernel<L, false, false, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);
     }
     return hipGetLastError();
 }

@@ -56,8 +56,9 @@ struct Context {
     hipDeviceProp_t prop{};
     hipStream_t stream = nullptr;       // library-owned stream (host-side helpers)
     Slot slots[kSlots];
-    int lanes = 8;                      // default schedule
+    int lanes = 4;                      // default schedule
     unsigned flags = 0;
+    unsigned extra_lds = 0;             // SWMI_EXTRA_LDS: occupancy sweep knob (BASELINE config 3)
     std::mutex mu;                      // serialises use of the slots
 };
 
@@ -96,6 +97,7 @@ LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows)
     cfg.lanes_per_alignment = g_ctx.lanes;
     cfg.use_i16 = (g_ctx.flags & swmi::kUseI16) != 0;
     cfg.use_lut = (g_ctx.flags & swmi::kUseLut) != 0;
+    cfg.extra_lds_bytes = g_ctx.extra_lds;
     bool fold = !(g_ctx.flags & swmi::kNoGapFold);
     for (int k = 0; k < 16 && fold; ++k) {
         const int v = int(sm[k]) + gap;
@@ -234,6 +236,8 @@ int swmi_init(int device)
     HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     for (auto &s : g_ctx.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     g_ctx.device = device;
+    const char *env_x = getenv("SWMI_EXTRA_LDS");
+    g_ctx.extra_lds = env_x ? (unsigned)atoi(env_x) : 0;
     const char *env_l = getenv("SWMI_LANES");
     if (env_l && swmi::schedule_supported(atoi(env_l))) g_ctx.lanes = atoi(env_l);
     g_ctx.ready = true;
@@ -262,7 +266,7 @@ int swmi_shutdown(void)
 
 int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
 {
-    if (lanes_per_alignment == 0) lanes_per_alignment = 8;
+    if (lanes_per_alignment == 0) lanes_per_alignment = 4;
     if (!swmi::schedule_supported(lanes_per_alignment))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
     if (flags & ~7u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
@@ -326,6 +330,28 @@ int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t se
     if (rc != SWMI_OK) return rc;
     HIP_TRY(hipSetDevice(g_ctx.device));
     return score_host_batch(seq1s, seq2, n_seq1, score_matrix, gap_penalty, scores, false, true);
+}
+
+int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void *d_seq2, const int8_t score_matrix[16],
+                                  int8_t gap_penalty, void *d_scores, void *stream)
+{
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (n_seq1 == 0) return SWMI_OK;
+    if (!d_seq1s || !d_seq2 || !d_scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n_seq1 = %zu", n_seq1);
+    if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2) | reinterpret_cast<uintptr_t>(d_scores)) & 15)
+        return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    SmRows rows;
+    const LaunchConfig cfg = make_config(score_matrix, gap_penalty, &rows);
+    for (size_t off = 0; off < n_seq1; off += kMaxLaunchPairs) {
+        const size_t m = n_seq1 - off < kMaxLaunchPairs ? n_seq1 - off : kMaxLaunchPairs;
+        HIP_TRY(swmi::launch_score_one_vs_many(cfg, static_cast<const uint8_t *>(d_seq1s) + off * kSeq,
+                                               static_cast<const uint8_t *>(d_seq2), static_cast<int32_t *>(d_scores) + off, m,
+                                               rows, gap_penalty, static_cast<hipStream_t>(stream)));
+    }
+    return SWMI_OK;
 }
 
 int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_packed, size_t n,

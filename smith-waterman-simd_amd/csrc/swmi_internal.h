@@ -22,6 +22,7 @@ struct LaunchConfig {
     int lanes_per_alignment;   // 64, 32, 16, 8, 4, 2
     bool fold_gap;             // rows carry sm + gap (requires every sm + gap to fit int8)
     bool use_i16;
+    unsigned extra_lds_bytes;  // unused dynamic LDS per workgroup: caps workgroups per CU (occupancy sweep, SWMI_EXTRA_LDS)
     bool use_lut;              // LDS score lookup instead of v_dot4 (gap-folded body only, L in {16, 8, 4})
 };
 

@@ -15,7 +15,7 @@ SEQ_LEN = 128
 PACKED_LEN = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libswmi.so")
+LIB_PATH = os.environ.get("SWMI_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libswmi.so"))   # SWMI_LIB: A/B builds (tools/)
 
 OK = 0
 ERR_NOT_INITIALIZED = -1
@@ -29,6 +29,7 @@ ERR_QUEUE_FULL = -8
 
 NO_GAP_FOLD = 1
 USE_I16 = 2
+USE_LUT = 4
 
 
 class SwmiError(RuntimeError):
@@ -61,6 +62,7 @@ def load():
     lib.swmi_score_batch.argtypes = [vp, vp, sz, vp, i8, vp]
     lib.swmi_score_batch_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
     lib.swmi_score_one_vs_many.argtypes = [vp, sz, vp, vp, i8, vp]
+    lib.swmi_score_one_vs_many_device.argtypes = [vp, sz, vp, vp, i8, vp, vp]
     lib.swmi_score_batch_packed.argtypes = [vp, vp, sz, vp, i8, vp]
     lib.swmi_score_batch_packed_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
     lib.swmi_unpack.argtypes = [vp, sz, vp]
@@ -188,6 +190,11 @@ def score_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores,
     sm = _sm(score_matrix)
     fn = load().swmi_score_batch_packed_device if packed else load().swmi_score_batch_device
     _check(fn(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream))
+
+
+def score_one_vs_many_device(d_seq1s, n, d_seq2, score_matrix, gap_penalty, d_scores, stream=0):
+    sm = _sm(score_matrix)
+    _check(load().swmi_score_one_vs_many_device(d_seq1s, n, d_seq2, sm.ctypes.data, int(gap_penalty), d_scores, stream))
 
 
 def generate_pairs_device(d_seq1s, d_seq2s, n, seed, first_pair=0, stream=0):

@@ -18,7 +18,7 @@ def _declared_symbols():
 def test_header_declares_the_expected_surface():
     syms = _declared_symbols()
     for must in ("swmi_init", "swmi_shutdown", "swmi_last_error", "swmi_score_pair", "swmi_score_batch",
-                 "swmi_score_batch_device", "swmi_score_one_vs_many", "swmi_score_batch_packed", "swmi_unpack",
+                 "swmi_score_batch_device", "swmi_score_one_vs_many", "swmi_score_one_vs_many_device", "swmi_score_batch_packed", "swmi_unpack",
                  "swmi_queue_create", "swmi_queue_submit", "swmi_queue_wait", "swmi_queue_destroy",
                  "swmi_set_schedule", "swmi_generate_pairs_device", "swmi_generate_pairs_host",
                  "swmi_time_batch_device", "swmi_get_device_info"):

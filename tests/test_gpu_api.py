@@ -59,6 +59,12 @@ def test_one_vs_many(gpu, oracle, golden):
     sm2 = match_matrix(5, -4)
     want = oracle.batch(a, np.repeat(b[:1], 5000, axis=0), sm2, 2)
     assert np.array_equal(gpu.score_one_vs_many(a, b[0], sm2, 2), want)
+    d1 = torch.from_numpy(a).cuda()
+    d2 = torch.from_numpy(b[0].copy()).cuda()
+    out = torch.empty(5000, dtype=torch.int32, device="cuda")
+    gpu.score_one_vs_many_device(d1.data_ptr(), 5000, d2.data_ptr(), sm2, 2, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
 
 
 def test_fixed_111_scorer_is_the_general_one(gpu, golden):

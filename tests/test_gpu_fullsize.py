@@ -44,7 +44,7 @@ def test_all_schedules_agree_on_one_million_pairs(gpu, resident):
     sm = match_matrix(1, -1)        # speedtest111x32 parameters, source.cpp:3202-3207
     ref = None
     try:
-        for lanes, flags in ((8, 0), (64, 0), (32, 1), (16, 2), (4, 3), (2, 0)):
+        for lanes, flags in ((4, 0), (64, 0), (32, 1), (16, 2), (4, 3), (8, 4), (8, 1), (2, 0)):
             gpu.set_schedule(lanes, flags)
             s = _score(gpu, d1, d2, sm, 1)
             if ref is None:

@@ -9,8 +9,10 @@ from conftest import match_matrix
 
 pytestmark = pytest.mark.gpu
 
-SCHEDULES = [(64, 0), (64, 1), (32, 0), (32, 3), (16, 0), (16, 1), (8, 0), (8, 1), (8, 2), (8, 3), (4, 0), (4, 1),
-             (4, 2), (2, 0), (2, 1)]
+# (lanes per alignment, flags): flags 0 = gap-folded cell when the matrix allows it, 1 = general cell,
+# 2 = 16-bit-max cell, 4 = LDS score-lookup kernel (falls back to the v_dot4 kernel where it does not apply)
+SCHEDULES = [(64, 0), (64, 1), (32, 0), (32, 3), (16, 0), (16, 1), (16, 4), (8, 0), (8, 1), (8, 2), (8, 3), (8, 4),
+             (4, 0), (4, 1), (4, 2), (4, 4), (2, 0), (2, 1)]
 
 
 @pytest.mark.parametrize("lanes,flags", SCHEDULES)

@@ -59,4 +59,9 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     summary["hbm_write_bytes"] = write_b
     summary["hbm_bytes_per_launch"] = fetch_b * 2.0 + write_b
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+if "hbm_bytes_per_launch" in summary and "SQ_WAVES" in summary:
+    # bench.py reads this for roofline.traffic (per launch of the default 1 048 576-pair step)
+    json.dump({"pairs_per_launch": 1 << 20, "hbm_bytes_per_launch": round(summary["hbm_bytes_per_launch"]),
+               "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % tag},
+              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1, sort_keys=True))
