@@ -92,3 +92,32 @@ def test_monotone_in_gap_and_bounded(gpu, resident):
         if prev is not None:
             assert bool((s <= prev).all())      # a larger gap penalty can never raise a score
         prev = s
+
+
+def test_host_batch_pipeline_across_chunks(gpu, oracle):
+    """swmi_score_batch stages host buffers in 1M-pair chunks on two alternating streams: cover > 2 chunks + ragged end."""
+    n = (1 << 21) + 12345
+    a, b = gpu.generate_pairs_host(n, 4242, 7)
+    sm = match_matrix(2, -3)
+    got = gpu.score_batch(a, b, sm, 5)
+    want = oracle.batch(a, b, sm, 5)
+    assert np.array_equal(got, want)
+
+
+def test_sixty_four_million_pairs_checksum(gpu, resident):
+    """BASELINE config 3 size (64M pairs, 16 GiB of inputs) on one GPU: every 1M-pair block of the big launch must
+    reproduce the scores of that block scored on its own (position independence at full size)."""
+    n = 1 << 26
+    d1 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    d2 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    gpu.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, 10000, 0, st)
+    sm = match_matrix(10, -30)
+    big = _score(gpu, d1, d2, sm, 15, n)
+    assert int(big[:N].to(torch.int64).sum().item()) == 79139805
+    for blk in (0, 17, 63):
+        part = torch.empty(N, dtype=torch.int32, device="cuda")
+        gpu.score_batch_device(d1.data_ptr() + blk * N * 128, d2.data_ptr() + blk * N * 128, N, sm, 15, part.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(part, big[blk * N:(blk + 1) * N])
+    assert int(big.min()) >= 30 and int(big.max()) <= 600

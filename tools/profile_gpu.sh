@@ -18,3 +18,6 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_V
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG --output-format csv -- $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG --output-format csv -- $BENCH > $OUT/pmc_write.log 2>&1 || echo "pmc_write failed"
 find $OUT -name "*.csv" | head -30
+# derived metrics (ROCm 7.2 has no gfx950 section in derived_counters.xml: these fall back to the gfx94x formulas)
+rocprofv3 --pmc VALUBusy VALUUtilization -d $OUT/pmc_derived -o $TAG --output-format csv -- $BENCH > $OUT/pmc_derived.log 2>&1 || echo "pmc_derived failed"
+rocprofv3 --pmc MemUnitBusy OccupancyPercent -d $OUT/pmc_derived2 -o $TAG --output-format csv -- $BENCH > $OUT/pmc_derived2.log 2>&1 || echo "pmc_derived2 failed"

@@ -47,7 +47,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
             summary["calls"] = int(r["Calls"])
             summary["avg_ns"] = float(r["AverageNs"])
             summary["min_ns"] = float(r["MinNs"])
-for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_derived", "pmc_derived2"):
     summary.update({k: round(v, 1) for k, v in per_kernel_avg(counter_rows(sub)).items()})
 if "SQ_BUSY_CYCLES" in summary and "SQ_ACTIVE_INST_VALU" in summary:
     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; SQ_BUSY_CYCLES per SE ... keep raw numbers, derive simple ratios
