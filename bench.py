@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30, help="untimed steps (the clock takes ~10 launches to settle after idle)")
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many"],
+    ap.add_argument("--len", type=int, default=1024, help="sequence length of the banded-affine mode")
+    ap.add_argument("--gap-open", type=int, default=5)
+    ap.add_argument("--gap-extend", type=int, default=1)
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many", "banded-affine"],
                     help="pairs = the headline path; packed = 2-bit inputs (SURVEY 8f N3); one-vs-many = every seq1 against "
                          "ONE seq2 (N1) -- secondary rows, same kernel, same contract")
     ap.add_argument("--pairs", type=int, default=1 << 20, help="pairs per GPU per step")
@@ -108,6 +111,69 @@ def cpu_baseline(swmi, np, args, gpu_scores_head, sample):
     return info
 
 
+def bench_banded(args, swmi, np, torch, local_rank):
+    """Secondary row: 1024 x 1024 affine gap, 128-diagonal band, one wavefront per alignment (single GPU)."""
+    length = args.len
+    P = args.pairs if args.pairs != (1 << 20) else 1 << 16
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    npairs128 = P * length // 128               # reuse the 128-mer generator: P len-mers = P*len/128 consecutive 128-mers
+    d1 = torch.empty(P * length, dtype=torch.uint8, device=dev)
+    d2 = torch.empty(P * length, dtype=torch.uint8, device=dev)
+    swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), npairs128, args.seed, 0, stream.cuda_stream)
+    # make seq2 a mutated copy of seq1 (~8 % substitutions) so that alignments are long: random-vs-random would idle in H = 0
+    mut = torch.rand(P * length, device=dev) < 0.08
+    d2 = torch.where(mut, d2, d1).contiguous()
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    sm = swmi.match_matrix(2, -3)
+
+    def launch():
+        swmi.score_banded_affine_device(d1.data_ptr(), d2.data_ptr(), P, length, sm, args.gap_open, args.gap_extend,
+                                        scores.data_ptr(), stream.cuda_stream)
+    for _ in range(args.warmup):
+        launch()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream); launch(); b.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    band_cells = sum(min(length, i + 63) - max(1, i - 64) + 1 for i in range(1, length + 1))
+    value = P * args.steps / elapsed
+    line = {"metric": "alignments/sec (and GCUPS), banded affine extension", "value": round(value, 1), "unit": "alignments/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "gcups": round(value * band_cells / 1e9, 1),
+            "config": {"workload": "BASELINE.json configs[4] (extension, parity unpinned by the reference): %d pairs of %d-mers, "
+                                   "128-diagonal band, sm 2/-3, gap open %d extend %d, inputs resident in HBM" % (
+                                       P, length, args.gap_open, args.gap_extend), "band_cells_per_alignment": band_cells},
+            "roofline": {"bound": "valu", "kernel": "sw_banded_affine_kernel", "kernel_ms": round(kernel_ms, 4),
+                         # 12 algorithmic int ops per cell: 4 sub, 2+3 max, 1 add, 1 running max, 1 lookup
+                         "achieved": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12, 3), "peak": round(VALU_PEAK_TOPS, 1),
+                         "unit": "TOP/s (int32)", "frac": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+                         "traffic": None},
+            "checksum": int(scores.to(torch.int64).sum().item())}
+    if not args.no_cpu_baseline:
+        sample = 256
+        a = d1[: sample * length].cpu().numpy().reshape(sample, length)
+        b = d2[: sample * length].cpu().numpy().reshape(sample, length)
+        orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        orc.sw_oracle_banded_affine.restype = ctypes.c_int
+        vp = ctypes.c_void_p
+        t0 = time.perf_counter()
+        want = np.array([orc.sw_oracle_banded_affine(a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), length,
+                                                     sm.ctypes.data_as(vp), args.gap_open, args.gap_extend) for k in range(sample)], np.int32)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"kind": "port", "function": "oracle/sw_oracle.c sw_oracle_banded_affine (scalar, full tables)",
+                                "value": round(sample / dt, 1), "unit": "alignments/s", "cores": 1,
+                                "sample": "first %d pairs of the batch" % sample,
+                                "gpu_mismatches": int((want != scores[:sample].cpu().numpy()).sum())}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +206,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.mode == "banded-affine":            # BASELINE configs[4] (extension, parity unpinned by the reference)
+        return bench_banded(args, swmi, np, torch, local_rank)
     P = args.pairs
     n_total = P * world
     lo, hi = sharding.shard_bounds(n_total, rank, world)        # contiguous shard of the global pair index space

@@ -119,6 +119,19 @@ SWMI_API int swmi_score_batch_packed_device(const void *d_seq1s_packed, const vo
                                             const int8_t score_matrix[16], int8_t gap_penalty,
                                             void *d_scores, void *stream);
 
+/* ---- extension: banded affine-gap scoring (BASELINE.json configs[4]; NO reference counterpart) -----------
+ * The reference has linear gaps and no band on this path, so this entry point replaces
+ * nothing in source.cpp; its semantics are defined by oracle/sw_oracle.c sw_oracle_banded_affine() and its
+ * parity is NOT pinned by the reference.  n pairs of `len`-mers (64 <= len <= 1792, pair k at byte offset
+ * len*k), local alignment restricted to the 128 diagonals -64 <= j - i <= 63, a gap of length k costs
+ * gap_open + (k-1)*gap_extend (both in [0,127]).  One wavefront per alignment, see DESIGN.md section 9. */
+SWMI_API int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int len,
+                                      const int8_t score_matrix[16], int gap_open, int gap_extend,
+                                      int32_t *scores);
+SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, size_t n, int len,
+                                             const int8_t score_matrix[16], int gap_open, int gap_extend,
+                                             void *d_scores, void *stream);
+
 /* unpack() itself (source.cpp:1580-1583) for n packed sequences, on the GPU. Host buffers. */
 SWMI_API int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked);
 

@@ -90,6 +90,56 @@ void swref_unpack(const uint8_t *src32, uint8_t *dst128)
     unpack(*reinterpret_cast<const std::array<uint8_t, 32> *>(src32), *reinterpret_cast<std::array<uint8_t, 128> *>(dst128));
 }
 
+// Semi-global adaptive-band X-drop family (source.cpp:1836-2725), SURVEY 8f row N4.
+// variant: 0 = scalar (:1836), 1 = _simd (:1978), 2 = _simd_mark2 (:2167), 3 = _simd_mark3 (:2355), 4 = _simd_mark4 (:2543).
+// traceback receives up to `cap` (i, j) pairs as 2 x int32 each; *len = number of pairs the reference returned.
+int swref_semiglobal(int variant, const uint8_t *seq1, const uint8_t *seq2, int32_t *score, int32_t *traceback,
+                     size_t cap, size_t *len)
+{
+    using Long = std::array<uint8_t, 16384>;
+    const Long &a = *reinterpret_cast<const Long *>(seq1);
+    const Long &b = *reinterpret_cast<const Long *>(seq2);
+    std::pair<int, std::vector<std::pair<int, int>>> r;
+    switch (variant) {
+    case 0: r = SemiGlobal_AdaptiveBanded_XDrop_111_32_70(a, b); break;
+    case 1: r = SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd(a, b); break;
+    case 2: r = SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd_mark2(a, b); break;
+    case 3: r = SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd_mark3(a, b); break;
+    case 4: r = SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd_mark4(a, b); break;
+    default: return -1;
+    }
+    *score = r.first;
+    *len = r.second.size();
+    for (size_t k = 0; k < r.second.size() && k < cap; ++k) {
+        traceback[2 * k] = r.second[k].first;
+        traceback[2 * k + 1] = r.second[k].second;
+    }
+    return 0;
+}
+
+// The reference's test inputs for that family (TestSemiGlobal, source.cpp:2734-2771): a random 16384-mer and a copy
+// with ~10 % substitutions, ~10 % insertions, ~10 % deletions; libstdc++ draw, `n` consecutive pairs of the stream.
+void swref_semiglobal_stream(uint64_t seed, size_t n, uint8_t *seq1s, uint8_t *seq2s)
+{
+    std::mt19937_64 rnd(seed);
+    std::uniform_int_distribution<int> dna(0, 3);
+    std::uniform_int_distribution<int> dice(0, 99);
+    for (size_t k = 0; k < n; ++k) {
+        uint8_t *a = seq1s + 16384 * k, *b = seq2s + 16384 * k;
+        for (int i = 0; i < 16384; ++i) a[i] = (uint8_t)dna(rnd);
+        for (int i = 0, j = 0; i < 16384;) {
+            if (j == 16384) b[i++] = (uint8_t)dna(rnd);
+            else {
+                const int p = dice(rnd);
+                if (p < 10) { b[i++] = (uint8_t)dna(rnd); ++j; }
+                else if (p < 20) { b[i++] = (uint8_t)dna(rnd); }
+                else if (p < 30) { ++j; }
+                else { b[i++] = a[j++]; }
+            }
+        }
+    }
+}
+
 // Input streams exactly as the reference drivers draw them (libstdc++ here):
 //   interleaved a[i], b[i] from mt19937_64(seed) + uniform_int_distribution<int>(0,3)
 //   -- SpeedTest source.cpp:3033-3040 (one pair), TestSimdSmithWaterman source.cpp:2944-2953 (a stream of pairs).

@@ -454,6 +454,113 @@ sw128_lut_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ 
     if (j == 0 && live) scores[pair] = best;
 }
 
+// ---- banded affine-gap scorer (BASELINE.json configs[4]: 1024 x 1024, band 128) --------------------------
+//
+// An extension without a reference counterpart (the reference has linear gaps only); semantics = oracle/sw_oracle.c
+// sw_oracle_banded_affine():  E/F/H Gotoh recurrences on the 128 diagonals -64 <= j - i <= 63, local (floor 0).
+//
+// One wavefront walks ONE alignment's anti-diagonals: lane m owns the two adjacent diagonals 2m and 2m+1 of the band and
+// alternates between them, so every lane computes exactly one in-band cell per step (a lane-per-diagonal layout would
+// idle half the lanes on every anti-diagonal).  Step 2u computes cell (i, j) on diagonal 2m, step 2u+1 cell (i, j+1) on
+// diagonal 2m+1, with i = 33 - m + u, j = u + m - 31 (1-based).  Neighbours:
+//   even step: left = lane m-1's odd diagonal (DPP wave_shr:1), up = the lane's own odd diagonal
+//   odd  step: left = the lane's own even diagonal,             up = lane m+1's even diagonal (DPP wave_shl:1)
+// The row scores (4 x int8 per base of seq1) and the column one-hots (seq2) are staged per alignment in LDS; they stream
+// through the lanes by one DPP shift per step, the new element entering at lane 0 / lane 63 from a broadcast LDS read.
+// E and F are kept saturated at 0 (v_sub_u32 clamp): max(0, E) is all H ever needs, and it makes every out-of-band or
+// out-of-matrix neighbour (which the DPP shifts and the pad entries deliver as 0) behave as -infinity.  Cells past the end
+// of either sequence keep computing; their values are bounded by the running maximum (open, ext >= 0), so nothing is masked.
+__device__ __forceinline__ int from_lane_below(int v)   // value of lane m-1, 0 into lane 0
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int from_lane_above(int v)   // value of lane m+1, 0 into lane 63
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
+                        uint32_t n, int len, SmRows rows, int gap_open, int gap_ext)
+{
+    extern __shared__ uint32_t lds_dyn[];       // per wave: row scores [len + 64] then column one-hots [len + 64]
+    __shared__ uint32_t lds_rows[kWavesPerBlock][4];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t pair = blockIdx.x * kWavesPerBlock + wv;
+    if (pair >= n) return;                      // wave-uniform; only wave-level synchronisation below
+    const int stride = len + 64;
+    uint32_t *arow = lds_dyn + (size_t)wv * 2 * stride;
+    uint32_t *boh = arow + stride;
+
+    if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t *s1 = seq1s + (size_t)pair * (size_t)len;
+    const uint8_t *s2 = seq2s + (size_t)pair * (size_t)len;
+    for (int k = lane; k < stride; k += 64) {
+        const bool in = k < len;
+        const uint32_t a = in ? (s1[k] & 3u) : 0u;
+        const uint32_t b = in ? (s2[k] & 3u) : 0u;
+        arow[k] = in ? lds_rows[wv][a] : 0x80808080u;     // pad rows score -128 against everything
+        boh[k] = in ? (1u << (8u * b)) : 0u;              // pad columns select nothing
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // state at u = 0: lane m sits at row i = 33 - m, column j = m - 31
+    int a_cur = lane <= 32 ? (int)arow[32 - lane] : (int)0x80808080u;
+    int b_cur = lane >= 32 ? (int)boh[lane - 32] : 0;
+    int h0 = 0, e0 = 0, f0 = 0;                 // last cell on the even diagonal 2m
+    int h1 = 0, e1 = 0, f1 = 0;                 // last cell on the odd diagonal 2m+1
+    int best = 0;
+    int b_in = (int)boh[32];                    // enters at lane 63 before the first odd step: column 33
+    int a_in = (int)arow[33];                   // enters at lane 0 before the second even step: row 34
+
+    for (int u = 0; u < len; ++u) {
+        const int b_in_next = (int)boh[u + 33];
+        const int a_in_next = (int)arow[u + 34 < stride ? u + 34 : stride - 1];
+        // even step: diagonal 2m, cell (i, j)
+        {
+            const int hl = from_lane_below(h1), el = from_lane_below(e1);
+            const int e = max(sat_sub<false>(el, gap_ext), sat_sub<false>(hl, gap_open));
+            const int f = max(sat_sub<false>(f1, gap_ext), sat_sub<false>(h1, gap_open));
+            const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
+            const int tf = t > f ? t : f;
+            h0 = tf > e ? tf : e;               // v_max3_i32; >= 0 because e, f >= 0
+            e0 = e;
+            f0 = f;
+        }
+        // the column stream advances: lane m takes lane m+1's one-hot, lane 63 the next column of seq2
+        b_cur = __builtin_amdgcn_update_dpp(b_in, b_cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        // odd step: diagonal 2m+1, cell (i, j+1)
+        {
+            const int hu = from_lane_above(h0), fu = from_lane_above(f0);
+            const int e = max(sat_sub<false>(e0, gap_ext), sat_sub<false>(h0, gap_open));
+            const int f = max(sat_sub<false>(fu, gap_ext), sat_sub<false>(hu, gap_open));
+            const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
+            const int tf = t > f ? t : f;
+            h1 = tf > e ? tf : e;
+            e1 = e;
+            f1 = f;
+        }
+        const int hb = h0 > h1 ? h0 : h1;
+        best = best > hb ? best : hb;
+        // the row stream advances: lane m takes lane m-1's row scores, lane 0 the next row of seq1
+        a_cur = __builtin_amdgcn_update_dpp(a_in, a_cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        b_in = b_in_next;
+        a_in = a_in_next;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(best, o);
+        best = best > other ? best : other;
+    }
+    if (lane == 0) scores[pair] = best;
+}
+
 // ---- synthetic input generator (specification in include/swmi.h) -----------------------------------
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
@@ -560,6 +667,18 @@ hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_se
                                     int32_t *d_scores, size_t n_seq1, const SmRows &rows, int gap, hipStream_t stream)
 {
     return launch_mode<2>(cfg, d_seq1s, d_seq2, d_scores, n_seq1, rows, gap, stream);
+}
+
+hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
+                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 64) * sizeof(uint32_t);
+    hipLaunchKernelGGL(sw_banded_affine_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, d_seq1s,
+                       d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    return hipGetLastError();
 }
 
 hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,

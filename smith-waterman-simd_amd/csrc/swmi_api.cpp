@@ -394,6 +394,70 @@ int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq
     return device_entry(d_seq1s_packed, d_seq2s_packed, n, score_matrix, gap_penalty, d_scores, stream, true);
 }
 
+static int check_banded(const int8_t *sm, int len, int open, int ext)
+{
+    if (!sm) return fail(SWMI_ERR_INVALID_ARGUMENT, "score_matrix is NULL");
+    if (len < 64 || len > 1792) return fail(SWMI_ERR_INVALID_ARGUMENT, "len %d outside [64, 1792]", len);
+    if (open < 0 || open > 127 || ext < 0 || ext > 127)
+        return fail(SWMI_ERR_DOMAIN, "gap_open %d / gap_extend %d outside [0,127]", open, ext);
+    return SWMI_OK;
+}
+
+int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, size_t n, int len,
+                                    const int8_t score_matrix[16], int gap_open, int gap_extend, void *d_scores, void *stream)
+{
+    int rc = check_banded(score_matrix, len, gap_open, gap_extend);
+    if (rc != SWMI_OK) return rc;
+    if (n == 0) return SWMI_OK;
+    if (!d_seq1s || !d_seq2s || !d_scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    const SmRows rows = pack_rows(score_matrix, 0);
+    const size_t max_launch = size_t(1) << 24;
+    for (size_t off = 0; off < n; off += max_launch) {
+        const size_t m = n - off < max_launch ? n - off : max_launch;
+        HIP_TRY(swmi::launch_banded_affine(static_cast<const uint8_t *>(d_seq1s) + off * size_t(len),
+                                           static_cast<const uint8_t *>(d_seq2s) + off * size_t(len),
+                                           static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend,
+                                           static_cast<hipStream_t>(stream)));
+    }
+    return SWMI_OK;
+}
+
+int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int len, const int8_t score_matrix[16],
+                             int gap_open, int gap_extend, int32_t *scores)
+{
+    int rc = check_banded(score_matrix, len, gap_open, gap_extend);
+    if (rc != SWMI_OK) return rc;
+    if (n == 0) return SWMI_OK;
+    if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    std::lock_guard<std::mutex> lock(g_ctx.mu);
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    // the slot buffers are sized in 128-byte pairs: a len-mer pair occupies ceil(len / 128) of them
+    const size_t per = (size_t(len) + kSeq - 1) / kSeq;
+    const size_t chunk_cap = kChunkPairs / per;
+    const size_t chunk = n < chunk_cap ? n : chunk_cap;
+    for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
+        rc = ensure_slot(g_ctx.slots[k], chunk * per);
+        if (rc != SWMI_OK) return rc;
+    }
+    size_t idx = 0;
+    for (size_t off = 0; off < n; off += chunk, ++idx) {
+        Slot &s = g_ctx.slots[idx % kSlots];
+        const size_t m = n - off < chunk ? n - off : chunk;
+        HIP_TRY(hipMemcpyAsync(s.d_seq1, seq1s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_seq2, seq2s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream));
+        rc = swmi_score_banded_affine_device(s.d_seq1, s.d_seq2, m, len, score_matrix, gap_open, gap_extend, s.d_scores, s.stream);
+        if (rc != SWMI_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(scores + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    }
+    for (int k = 0; k < kSlots; ++k)
+        if (g_ctx.slots[k].stream) HIP_TRY(hipStreamSynchronize(g_ctx.slots[k].stream));
+    return SWMI_OK;
+}
+
 int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
 {
     if (n_seqs == 0) return SWMI_OK;

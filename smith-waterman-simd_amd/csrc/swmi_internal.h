@@ -32,6 +32,9 @@ hipError_t launch_score(const LaunchConfig &cfg, const uint8_t *d_seq1s, const u
 // Score n_seq1 sequences against one seq2 (device pointers; d_seq2 = 128 bytes).
 hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_seq1s, const uint8_t *d_seq2,
                                     int32_t *d_scores, size_t n_seq1, const SmRows &rows, int gap, hipStream_t stream);
+// Banded (128 diagonals) affine-gap local alignment of n pairs of `len`-mers (device pointers).
+hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
+                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream);
 hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,
                            hipStream_t stream);
 hipError_t launch_unpack(const uint8_t *d_packed, uint8_t *d_unpacked, size_t n_seqs, hipStream_t stream);

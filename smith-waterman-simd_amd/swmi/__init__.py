@@ -66,6 +66,8 @@ def load():
     lib.swmi_score_batch_packed.argtypes = [vp, vp, sz, vp, i8, vp]
     lib.swmi_score_batch_packed_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
     lib.swmi_unpack.argtypes = [vp, sz, vp]
+    lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.swmi_score_banded_affine_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.swmi_queue_create.argtypes = [sz, vp, i8, ctypes.POINTER(vp)]
     lib.swmi_queue_submit.argtypes = [vp, vp, vp]
     lib.swmi_queue_submit.restype = ctypes.c_longlong
@@ -169,6 +171,26 @@ def score_batch_packed(seq1s_packed, seq2s_packed, score_matrix, gap_penalty):
     out = np.zeros(n, np.int32)
     _check(load().swmi_score_batch_packed(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
     return out
+
+
+def score_banded_affine(seq1s, seq2s, score_matrix, gap_open, gap_extend):
+    """Extension (BASELINE configs[4]): banded (128 diagonals) affine-gap local scores of n pairs of len-mers."""
+    a = np.ascontiguousarray(seq1s, dtype=np.uint8)
+    b = np.ascontiguousarray(seq2s, dtype=np.uint8)
+    if a.shape != b.shape or a.ndim != 2:
+        raise ValueError("seq1s and seq2s must both be (n, len)")
+    n, length = a.shape
+    sm = _sm(score_matrix)
+    out = np.zeros(n, np.int32)
+    _check(load().swmi_score_banded_affine(a.ctypes.data, b.ctypes.data, n, length, sm.ctypes.data, int(gap_open),
+                                           int(gap_extend), out.ctypes.data))
+    return out
+
+
+def score_banded_affine_device(d_seq1s, d_seq2s, n, length, score_matrix, gap_open, gap_extend, d_scores, stream=0):
+    sm = _sm(score_matrix)
+    _check(load().swmi_score_banded_affine_device(d_seq1s, d_seq2s, n, length, sm.ctypes.data, int(gap_open),
+                                                  int(gap_extend), d_scores, stream))
 
 
 def unpack(packed):

@@ -55,6 +55,16 @@ class Oracle:
         self.lib.sw_oracle_batch(self._p(a), self._p(b), ctypes.c_size_t(n), self._p(m), int(gap), self._p(out))
         return out
 
+    def banded_affine(self, seq1s, seq2s, sm, gap_open, gap_extend):
+        a = np.ascontiguousarray(seq1s, np.uint8)
+        b = np.ascontiguousarray(seq2s, np.uint8)
+        m = np.ascontiguousarray(sm, np.int8)
+        n, length = a.shape
+        out = np.zeros(n, np.int32)
+        self.lib.sw_oracle_banded_affine_batch(self._p(a), self._p(b), ctypes.c_size_t(n), int(length), self._p(m),
+                                               int(gap_open), int(gap_extend), self._p(out))
+        return out
+
     def generate(self, n, seed, first_pair=0):
         a = np.zeros((n, 128), np.uint8)
         b = np.zeros((n, 128), np.uint8)
