@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--len", type=int, default=1024, help="sequence length of the banded-affine mode")
     ap.add_argument("--gap-open", type=int, default=5)
     ap.add_argument("--gap-extend", type=int, default=1)
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many", "banded-affine"],
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many", "banded-affine", "semiglobal"],
                     help="pairs = the headline path; packed = 2-bit inputs (SURVEY 8f N3); one-vs-many = every seq1 against "
                          "ONE seq2 (N1) -- secondary rows, same kernel, same contract")
     ap.add_argument("--pairs", type=int, default=1 << 20, help="pairs per GPU per step")
@@ -174,6 +174,72 @@ def bench_banded(args, swmi, np, torch, local_rank):
     return 0
 
 
+def bench_semiglobal(args, swmi, np, torch, local_rank):
+    """Secondary row: the reference's semi-global adaptive-band X-drop aligner incl. traceback (single GPU).
+    Inputs follow SpeedtestSemiGlobal (source.cpp:2805-2813): a random 16384-mer and a copy with 5 % substitutions."""
+    L = 16384
+    P = args.pairs if args.pairs != (1 << 20) else 4096
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    g = torch.Generator(device=dev); g.manual_seed(args.seed)
+    d1 = torch.randint(0, 4, (P, L), dtype=torch.uint8, device=dev, generator=g)
+    rnd = torch.randint(0, 4, (P, L), dtype=torch.uint8, device=dev, generator=g)
+    keep = torch.rand((P, L), device=dev, generator=g) < 0.95
+    d2 = torch.where(keep, d1, rnd).contiguous()
+    cap = 32769
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    lengths = torch.empty(P, dtype=torch.int32, device=dev)
+    tb = torch.empty((P, cap, 2), dtype=torch.int32, device=dev)
+
+    def launch():
+        swmi.semiglobal_xdrop_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(),
+                                     stream.cuda_stream)
+    steps, warm = min(args.steps, 10), min(args.warmup, 2)
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        launch()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = P * steps / elapsed
+    line = {"metric": "alignments/sec, semi-global adaptive-band X-drop with traceback (SURVEY 8f N4)", "value": round(value, 1),
+            "unit": "alignments/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(elapsed * 1e3 / steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "SemiGlobal_AdaptiveBanded_XDrop_111_32_70 (source.cpp:1836): %d pairs of 16384-mers, 5 %% "
+                                   "substitutions (SpeedtestSemiGlobal inputs), band 32, X-drop 70, score + full traceback, "
+                                   "inputs resident in HBM" % P},
+            "mean_score": float(scores.float().mean().item()), "mean_traceback_len": float(lengths.float().mean().item())}
+    if not args.no_cpu_baseline:
+        ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
+        sample = 64
+        a = d1[:sample].cpu().numpy(); b = d2[:sample].cpu().numpy()
+        vp = ctypes.c_void_p
+        tbh = np.zeros((40000, 2), np.int32)
+        got_scores = scores[:sample].cpu().numpy(); got_len = lengths[:sample].cpu().numpy(); got_tb = tb[:sample].cpu().numpy()
+        mism = 0
+        if os.path.exists(ref_path):
+            ref = ctypes.CDLL(ref_path)
+            res = {}
+            for variant, name in ((1, "simd"), (4, "simd_mark4")):
+                t0 = time.perf_counter()
+                for k in range(sample):
+                    sc, ln = ctypes.c_int32(), ctypes.c_size_t()
+                    ref.swref_semiglobal(variant, a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), ctypes.byref(sc),
+                                         tbh.ctypes.data_as(vp), ctypes.c_size_t(40000), ctypes.byref(ln))
+                    if variant == 4:
+                        ok = sc.value == got_scores[k] and ln.value == got_len[k] and np.array_equal(tbh[: ln.value], got_tb[k, : ln.value])
+                        mism += 0 if ok else 1
+                res[name] = sample / (time.perf_counter() - t0)
+            line["cpu_baseline"] = {"kind": "reference", "function": "SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd_mark4 (source.cpp:2543), g++ -O3 -mavx2",
+                                    "value": round(res["simd_mark4"], 1), "unit": "alignments/s", "cores": 1,
+                                    "simd_variant_alignments_per_s": round(res["simd"], 1),
+                                    "sample": "first %d pairs of the batch" % sample, "gpu_mismatches": mism}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,6 +274,8 @@ def main():
 
     if args.mode == "banded-affine":            # BASELINE configs[4] (extension, parity unpinned by the reference)
         return bench_banded(args, swmi, np, torch, local_rank)
+    if args.mode == "semiglobal":
+        return bench_semiglobal(args, swmi, np, torch, local_rank)
     P = args.pairs
     n_total = P * world
     lo, hi = sharding.shard_bounds(n_total, rank, world)        # contiguous shard of the global pair index space

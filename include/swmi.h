@@ -132,6 +132,23 @@ SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_
                                              const int8_t score_matrix[16], int gap_open, int gap_extend,
                                              void *d_scores, void *stream);
 
+/* ---- semi-global adaptive-band X-drop aligner -------------------------------------
+ * Replaces SemiGlobal_AdaptiveBanded_XDrop_111_32_70 and its _simd / _simd_mark2..4 variants
+ * (source.cpp:1836-1976, :1978-2725; call sites TestSemiGlobal :2774-2778, SpeedtestSemiGlobal :2818-2856):
+ * two 16384-mers per alignment (alignment k at byte offset 16384*k), match +1 / mismatch -1 / gap -1, band of 32,
+ * X-drop 70, result = (score, traceback).  scores[k] = .first; tracebacks + k*cap*2 receives the (i, j) pairs of
+ * .second in the reference's order (from (0,0) to the best cell), at most `cap` of them; lengths[k] = .second.size()
+ * (<= 32769).  Host buffers.  Where the reference reads one byte past its padded sequences (the band at the very
+ * last position, source.cpp:1917-1919) this implementation reads a pad. */
+#define SWMI_SG_LEN 16384
+#define SWMI_SG_MAX_TRACEBACK 32769
+SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
+                                   int32_t *tracebacks, size_t cap, uint32_t *lengths);
+/* Same with every buffer resident in device memory; asynchronous on `stream`.  The library keeps a per-process
+ * workspace of ~0.33 MB per alignment (2-bit predecessor codes + band rows), grown on demand. */
+SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
+                                          void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
+
 /* unpack() itself (source.cpp:1580-1583) for n packed sequences, on the GPU. Host buffers. */
 SWMI_API int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked);
 

@@ -1,0 +1,251 @@
+// sg_kernels.hip -- gfx950 kernels for the reference's semi-global adaptive-band X-drop aligner
+//     SemiGlobal_AdaptiveBanded_XDrop_111_32_70   (source.cpp:1836-1976; SIMD variants :1978-2725)
+// SURVEY.md section 8f row N4.  Same results as the reference: (score, traceback from (0,0) to the best cell).
+//
+// Not a translation of the AVX2 variants (one 32-byte vector per anti-diagonal, u8 cells re-based every round,
+// source.cpp:2099-2109).  Here:
+//   * forward sweep: 32 lanes = the 32 cells of the band (BANDWIDTH, source.cpp:1848), two alignments per wavefront; cell values stay int32 with the
+//     reference's +70 offset (0 = dropped).  The band's direction (right / down) is decided per alignment every round
+//     from its two end lanes; the shifted neighbours come from cross-lane reads.  Instead of the reference's 4 MB table
+//     of cell values per alignment (source.cpp:1876) the sweep stores, per round, only what the traceback needs:
+//     a 2-bit predecessor code per lane (diag / up / left in the reference's own tie-break order :1962-1971) and the row
+//     of the band's top lane -- 10 bytes per round instead of 128.
+//   * traceback: one thread per alignment follows the codes back to (0,0) (twice: once to count, once to emit the
+//     positions in ascending order, as the reference returns them).
+#include "swmi_internal.h"
+
+namespace swmi {
+namespace {
+
+constexpr int kLen = 16384;                 // std::array<uint8_t,16384>, source.cpp:1837-1838
+constexpr int kXDrop = 70;                  // X_THRESHOLD, source.cpp:1848
+constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
+
+// max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
+__device__ __forceinline__ int row16_max(int v)
+{
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x141 /* row_half_mirror */, 0xf, 0xf, true);    v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x140 /* row_mirror */, 0xf, 0xf, true);         v = v > o ? v : o;
+    return v;
+}
+
+__device__ __forceinline__ int sat_dec(int v)             // max(v - 1, 0) for v >= 0: v_sub_u32 ... clamp
+{
+    return (int)__builtin_elementwise_sub_sat((unsigned)v, 1u);
+}
+
+__device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from turning `x & mask` into a v_cndmask
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// codes[(a * kMaxRound + r) * 2 + {0,1}]: bit k of word 0 / word 1 = low / high bit of lane k's predecessor code
+// (0 none or dropped, 1 diagonal, 2 up, 3 left); top_y[a * kMaxRound + r] = row of lane 31 in round r;
+// summary[a] = {score, best_round, best_lane, rounds stored}
+//
+// A round is one long dependency chain and the kernel is bound by how many instructions it issues per round (8 waves
+// per SIMD keep the issue port busy), so the body is branch-free and every cross-lane step is a DPP move or a v_readlane:
+// an LDS-crossbar shuffle (__shfl*, ds_bpermute_b32) costs more than all of a round's arithmetic.  The predecessor codes
+// fall out of three v_cmp masks combined on the scalar unit (the masks ARE the ballots).
+__global__ void __launch_bounds__(256)
+sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
+                  uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = lane & 31;                              // lane of the band, as the reference numbers them
+    const bool second = lane >= 32;                       // which of the wavefront's two alignments
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t a = wave * 2 + (second ? 1u : 0u);
+    if (wave * 2 >= n) return;
+    const bool real = a < n;
+    if (!real) a = n - 1;                                 // odd tail: shadow the last alignment, store nothing
+    const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
+    uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kMaxRound;
+    uint16_t *my_top = top_y + (size_t)a * kMaxRound;
+    const int not_first = keep_opaque(k == 0 ? 0 : -1), not_last = keep_opaque(k == 31 ? 0 : -1);
+    const bool writer = real && k == 0;
+
+    int cur = k == 31 ? kXDrop : 0, hor = 0, ver = 0, dia = 0;
+    int pos_x = 31;                                       // the reference's now_pos_x (31 leading pads); now_pos_y = round - (pos_x - 31)
+    int best = kXDrop, best_round = 0, best_lane = 31;
+    bool alive = true;
+    int rounds = 1;
+    if (writer) { my_codes[0] = make_uint2(0, 0); my_top[0] = 0; }
+
+    for (int round = 1; round < kMaxRound; ++round) {
+        if (!__any(alive)) break;
+        // direction of each alignment's band: lane 0 against lane 31 (source.cpp:1895)
+        const bool right_a = __builtin_amdgcn_readlane(cur, 0) < __builtin_amdgcn_readlane(cur, 31);
+        const bool right_b = __builtin_amdgcn_readlane(cur, 32) < __builtin_amdgcn_readlane(cur, 63);
+        const bool right = second ? right_b : right_a;
+        const int from_above = __builtin_amdgcn_update_dpp(0, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) & not_last;   // cur[k+1]
+        const int from_below = __builtin_amdgcn_update_dpp(0, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) & not_first;  // cur[k-1]
+        dia = right ? ver : hor;                          // :1897 / :1908
+        const int nh = right ? cur : from_below;          // :1898 / :1910-1911
+        const int nv = right ? from_above : cur;          // :1899-1900 / :1909
+        hor = nh;
+        ver = nv;
+        pos_x += right ? 1 : 0;
+        const int pos_y = round - (pos_x - 31);
+        const bool inside = pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;      // :1903, :1913: checked before the round is stored
+        alive = alive && inside;
+        const int i1 = pos_y + 30 - k;                    // 0-based index into seq1 of this lane's row y = pos_y + 31 - k
+        const int i2 = pos_x - 63 + k;                    // 0-based index into seq2 of this lane's column x = pos_x - 62 + k
+        const int l1 = seq1s[seq_base + (uint32_t)min(max(i1, 0), kLen - 1)];
+        const int l2 = seq2s[seq_base + (uint32_t)min(max(i2, 0), kLen - 1)];
+        const int c1 = (unsigned)i1 < (unsigned)kLen ? l1 : 0xF0;             // pads, source.cpp:1861-1873
+        const int c2 = (unsigned)i2 < (unsigned)kLen ? l2 : 0xF1;
+        const int s = (c1 == c2 && c1 < 4) ? 1 : -1;      // :1918-1920 (a pad never equals anything)
+        const int vd = dia != 0 ? dia + s : 0;            // :1922
+        const int vu = sat_dec(ver);                      // :1924, 0 stays 0
+        const int vl = sat_dec(hor);                      // :1923
+        const int m1 = vd > vu ? vd : vu;
+        const int v0 = m1 > vl ? m1 : vl;                 // >= 0
+        const int rm = row16_max(v0);
+        const int best_a = max(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
+        const int best_b = max(__builtin_amdgcn_readlane(rm, 32), __builtin_amdgcn_readlane(rm, 48));
+        const int round_best = second ? best_b : best_a;
+        const int gain = alive ? round_best : 0;
+        const bool improved = gain > best;                // :1933-1936
+        const unsigned long long hit = __ballot(v0 == round_best);
+        const unsigned mine = second ? (unsigned)(hit >> 32) : (unsigned)hit;
+        best = improved ? gain : best;
+        best_round = improved ? round : best_round;
+        best_lane = improved ? 31 - __builtin_clz(mine) : best_lane;          // the search of :1957-1958 walks down from lane 31
+        const int v = v0 < best - kXDrop ? 0 : v0;        // :1938-1941
+        // predecessor code in the reference's tie-break order (diag, up, left; :1962-1971): 1 / 2 / 3, 0 for a dropped cell.
+        // v != 0 && vd == v implies dia != 0 (and likewise for up), so three compare masks are enough.
+        const unsigned long long m_nz = __ballot(v != 0), m_d = __ballot(vd == v), m_u = __ballot(vu == v);
+        const unsigned long long bit0 = m_nz & (m_d | ~m_u), bit1 = m_nz & ~m_d;
+        if (alive && writer) {
+            my_codes[round] = second ? make_uint2((unsigned)(bit0 >> 32), (unsigned)(bit1 >> 32))
+                                     : make_uint2((unsigned)bit0, (unsigned)bit1);
+            my_top[round] = (uint16_t)pos_y;
+        }
+        cur = alive ? v : cur;
+        rounds = alive ? round + 1 : rounds;
+        alive = alive && round_best != 0;                 // :1943-1946
+    }
+    if (writer) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
+}
+
+// Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
+// 64 consecutive rounds of (code words, band row) each, fetched with coalesced loads one block ahead of the walker, and
+// the walker picks its round with v_readlane.  Two walks: the first counts the steps, the second writes the positions
+// at their final (ascending) index, 64 at a time.
+__global__ void __launch_bounds__(64)
+sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
+                    const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
+                    uint32_t cap, uint32_t *__restrict__ lengths)
+{
+    const uint32_t a = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kMaxRound;
+    const uint16_t *my_top = top_y + (size_t)a * kMaxRound;
+    const int4 sum = summary[a];
+    const int y0 = (int)my_top[sum.y] + 31 - sum.z;
+    const int x0 = sum.y - y0;
+    int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
+
+    // With room for the longest possible path the positions are written once, in walking (descending) order, and the
+    // wavefront reverses them in place afterwards; a smaller `cap` needs the count first (two walks).
+    const bool one_walk = cap >= (uint32_t)kMaxRound;
+    uint32_t total = 0;
+    for (int pass = one_walk ? 1 : 0; pass < 2; ++pass) {
+        int y = y0, x = x0;
+        int base = ((y + x) >> 6) << 6;                   // lanes hold rounds base .. base+63 (cur) and base-64 .. base-1 (nxt)
+        auto fetch = [&](int b, uint2 &cw, int &tw) {
+            const int r = b + lane;
+            const bool ok = b >= 0 && r < kMaxRound;
+            cw = ok ? my_codes[r] : make_uint2(0, 0);
+            tw = ok ? (int)my_top[r] : 0;
+        };
+        uint2 cw, nw;
+        int tw, nt;
+        fetch(base, cw, tw);
+        fetch(base - 64, nw, nt);
+        uint32_t count = 0;                               // positions emitted so far (descending order)
+        int by = 0, bx = 0;                               // this lane's slot of the 64-position output buffer
+        bool more = true;
+        while (more) {
+            // record the current position in slot count % 64
+            const int slot = (int)(count & 63u);
+            if (lane == slot) { by = y; bx = x; }
+            ++count;
+            more = (y | x) != 0;
+            if (more) {
+                const int r = y + x;
+                if (r < base) {                           // walked off the block: take the prefetched one, prefetch the next
+                    base -= 64;
+                    cw = nw; tw = nt;
+                    fetch(base - 64, nw, nt);
+                }
+                const int idx = __builtin_amdgcn_readfirstlane(r - base);
+                const unsigned lo = __builtin_amdgcn_readlane(cw.x, idx), hi = __builtin_amdgcn_readlane(cw.y, idx);
+                const int top = __builtin_amdgcn_readlane(tw, idx);
+                const int bl = 31 - (y - top);
+                const int code = (int)((lo >> bl) & 1u) | (int)(((hi >> bl) & 1u) << 1);
+                if (code == 1) { --y; --x; }
+                else if (code == 2) { --y; }
+                else if (code == 3) { --x; }
+                else more = false;                        // cannot happen for a cell on a live path
+            }
+            if (pass == 1 && (slot == 63 || !more)) {     // flush 64 buffered positions with one coalesced store
+                const uint32_t c = count - 1 - (uint32_t)slot + (uint32_t)lane;   // element number of this lane's slot
+                if (lane <= slot) {
+                    const uint32_t idx_out = one_walk ? c : total - 1 - c;
+                    if (idx_out < cap) out[idx_out] = make_int2(by, bx);
+                }
+            }
+        }
+        total = count;
+    }
+    if (one_walk) {                                       // reverse out[0 .. total) in place
+        __syncthreads();                                  // one wavefront per block: orders the stores above before the loads below
+        for (uint32_t i = (uint32_t)lane; i < total / 2; i += 64) {
+            const int2 lo_v = out[i], hi_v = out[total - 1 - i];
+            out[i] = hi_v;
+            out[total - 1 - i] = lo_v;
+        }
+    }
+    if (lane == 0) { scores[a] = sum.x; lengths[a] = total; }
+}
+
+}  // namespace
+
+namespace {
+inline size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
+inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kMaxRound * 2 * sizeof(uint32_t)); }
+inline size_t top_bytes(size_t n) { return round16(n * (size_t)kMaxRound * sizeof(uint16_t)); }
+}  // namespace
+
+size_t semiglobal_workspace_bytes(size_t n)
+{
+    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4));
+}
+
+hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
+                             int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    char *ws = static_cast<char *>(d_workspace);
+    uint32_t *codes = reinterpret_cast<uint32_t *>(ws);
+    uint16_t *top = reinterpret_cast<uint16_t *>(ws + codes_bytes(n));
+    int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + top_bytes(n));
+    // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
+    // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
+    const unsigned waves = (unsigned)((n + 1) / 2);
+    hipLaunchKernelGGL(sg_forward_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes,
+                       top, summary);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sg_traceback_kernel, dim3((unsigned)n), dim3(64), 0, stream, (uint32_t)n, codes, top, summary, d_scores,
+                       d_tracebacks, (uint32_t)cap, d_lengths);
+    return hipGetLastError();
+}
+
+}  // namespace swmi

@@ -58,6 +58,8 @@ struct Context {
     Slot slots[kSlots];
     int lanes = 4;                      // default schedule
     unsigned flags = 0;
+    void *sg_workspace = nullptr;       // semi-global aligner workspace (device), grown on demand
+    size_t sg_workspace_bytes = 0;
     unsigned extra_lds = 0;             // SWMI_EXTRA_LDS: occupancy sweep knob (BASELINE config 3)
     std::mutex mu;                      // serialises use of the slots
 };
@@ -259,6 +261,9 @@ int swmi_shutdown(void)
     }
     if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
     g_ctx.stream = nullptr;
+    if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
+    g_ctx.sg_workspace = nullptr;
+    g_ctx.sg_workspace_bytes = 0;
     g_ctx.ready = false;
     g_ctx.device = -1;
     return SWMI_OK;
@@ -455,6 +460,72 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
     }
     for (int k = 0; k < kSlots; ++k)
         if (g_ctx.slots[k].stream) HIP_TRY(hipStreamSynchronize(g_ctx.slots[k].stream));
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
+                                 size_t cap, void *d_lengths, void *stream)
+{
+    if (n == 0) return SWMI_OK;
+    if (!d_seq1s || !d_seq2s || !d_scores || !d_lengths || (!d_tracebacks && cap != 0))
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    if (n > (size_t(1) << 18)) return fail(SWMI_ERR_INVALID_ARGUMENT, "at most 2^18 alignments per call (got %zu)", n);
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx.mu);
+        const size_t need = swmi::semiglobal_workspace_bytes(n);
+        if (need > g_ctx.sg_workspace_bytes) {
+            HIP_TRY(hipDeviceSynchronize());              // the old workspace may still be in use by an earlier launch
+            if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
+            g_ctx.sg_workspace = nullptr;
+            g_ctx.sg_workspace_bytes = 0;
+            HIP_TRY(hipMalloc(&g_ctx.sg_workspace, need));
+            g_ctx.sg_workspace_bytes = need;
+        }
+    }
+    HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n,
+                                    g_ctx.sg_workspace, static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks),
+                                    cap, static_cast<uint32_t *>(d_lengths), static_cast<hipStream_t>(stream)));
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, int32_t *tracebacks,
+                          size_t cap, uint32_t *lengths)
+{
+    if (n == 0) return SWMI_OK;
+    if (!seq1s || !seq2s || !scores || !lengths || (!tracebacks && cap != 0))
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    std::lock_guard<std::mutex> lock(g_ctx.mu);
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    constexpr size_t kLen = SWMI_SG_LEN;
+    const size_t chunk = n < 2048 ? n : 2048;           // ~0.33 MB of workspace + cap*8 B of output per alignment
+    uint8_t *d1 = nullptr, *d2 = nullptr;
+    void *ws = nullptr;
+    int32_t *d_scores = nullptr, *d_tb = nullptr;
+    uint32_t *d_len = nullptr;
+    hipStream_t st = g_ctx.slots[0].stream;
+    hipError_t e = hipMalloc(&d1, chunk * kLen);
+    if (e == hipSuccess) e = hipMalloc(&d2, chunk * kLen);
+    if (e == hipSuccess) e = hipMalloc(&ws, swmi::semiglobal_workspace_bytes(chunk));
+    if (e == hipSuccess) e = hipMalloc(&d_scores, chunk * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_len, chunk * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_tb, (chunk * (cap ? cap : 1)) * 2 * sizeof(int32_t));
+    for (size_t off = 0; e == hipSuccess && off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        e = hipMemcpyAsync(d1, seq1s + off * kLen, m * kLen, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2, seq2s + off * kLen, m * kLen, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = swmi::launch_semiglobal(d1, d2, m, ws, d_scores, d_tb, cap, d_len, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(scores + off, d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(lengths + off, d_len, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && cap)
+            e = hipMemcpyAsync(tracebacks + off * cap * 2, d_tb, m * cap * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(ws); (void)hipFree(d_scores); (void)hipFree(d_len); (void)hipFree(d_tb);
+    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_semiglobal_xdrop: %s", hipGetErrorString(e));
     return SWMI_OK;
 }
 

@@ -66,6 +66,8 @@ def load():
     lib.swmi_score_batch_packed.argtypes = [vp, vp, sz, vp, i8, vp]
     lib.swmi_score_batch_packed_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
     lib.swmi_unpack.argtypes = [vp, sz, vp]
+    lib.swmi_semiglobal_xdrop.argtypes = [vp, vp, sz, vp, vp, sz, vp]
+    lib.swmi_semiglobal_xdrop_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
     lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
     lib.swmi_score_banded_affine_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.swmi_queue_create.argtypes = [sz, vp, i8, ctypes.POINTER(vp)]
@@ -191,6 +193,29 @@ def score_banded_affine_device(d_seq1s, d_seq2s, n, length, score_matrix, gap_op
     sm = _sm(score_matrix)
     _check(load().swmi_score_banded_affine_device(d_seq1s, d_seq2s, n, length, sm.ctypes.data, int(gap_open),
                                                   int(gap_extend), d_scores, stream))
+
+
+SG_LEN = 16384
+SG_MAX_TRACEBACK = 32769
+
+
+def semiglobal_xdrop(seq1s, seq2s, cap=SG_MAX_TRACEBACK):
+    """Mirror of SemiGlobal_AdaptiveBanded_XDrop_111_32_70 (source.cpp:1836-1976) for n pairs of 16384-mers.
+
+    Returns (scores[n], list of n (len_k, 2) int32 arrays = the reference's traceback vectors)."""
+    a = np.ascontiguousarray(seq1s, dtype=np.uint8).reshape(-1, SG_LEN)
+    b = np.ascontiguousarray(seq2s, dtype=np.uint8).reshape(-1, SG_LEN)
+    n = a.shape[0]
+    scores = np.zeros(n, np.int32)
+    lengths = np.zeros(n, np.uint32)
+    tb = np.zeros((n, cap, 2), np.int32)
+    _check(load().swmi_semiglobal_xdrop(a.ctypes.data, b.ctypes.data, n, scores.ctypes.data, tb.ctypes.data, cap,
+                                        lengths.ctypes.data))
+    return scores, [tb[k, : min(int(lengths[k]), cap)].copy() for k in range(n)], lengths
+
+
+def semiglobal_xdrop_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream=0):
+    _check(load().swmi_semiglobal_xdrop_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream))
 
 
 def unpack(packed):

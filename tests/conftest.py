@@ -65,6 +65,17 @@ class Oracle:
                                                int(gap_open), int(gap_extend), self._p(out))
         return out
 
+    def semiglobal(self, seq1, seq2):
+        """(score, traceback[(len, 2)]) of oracle/sg_oracle.c for one pair of 16384-mers."""
+        a = np.ascontiguousarray(seq1, np.uint8)
+        b = np.ascontiguousarray(seq2, np.uint8)
+        tb = np.zeros((32769, 2), np.int32)
+        score, ln, oob = ctypes.c_int32(), ctypes.c_size_t(), ctypes.c_int()
+        rc = self.lib.sg_oracle_xdrop(self._p(a), self._p(b), ctypes.byref(score), self._p(tb), ctypes.c_size_t(32769),
+                                      ctypes.byref(ln), ctypes.byref(oob))
+        assert rc == 0, "sg_oracle_xdrop failed (%d)" % rc
+        return score.value, tb[: ln.value].copy()
+
     def generate(self, n, seed, first_pair=0):
         a = np.zeros((n, 128), np.uint8)
         b = np.zeros((n, 128), np.uint8)

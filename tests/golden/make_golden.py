@@ -213,6 +213,46 @@ def main():
         ref.swref_unpack(P(packed[k], u8p), P(unpacked[k], u8p))
     np.savez_compressed(os.path.join(HERE, "f5_siblings.npz"), seq1=a5, seq2=b5, scores_111=s111,
                         scores_111x32=x32, packed=packed, unpacked=unpacked)
+    # F6: semi-global adaptive-band X-drop aligner (source.cpp:1836-2725), SURVEY 8f row N4.  Scalar and the four SIMD
+    # variants must return the same (score, traceback); the traceback is stored as one move code per step
+    # (1 = diagonal, 2 = down (i+1), 3 = right (j+1)) from (0,0).
+    n6 = 8
+    g1 = np.zeros((n6, 16384), np.uint8)
+    g2 = np.zeros((n6, 16384), np.uint8)
+    ref.swref_semiglobal_stream(ctypes.c_uint64(10000), ctypes.c_size_t(n6), P(g1, u8p), P(g2, u8p))   # TestSemiGlobal inputs
+    base = rng.integers(0, 4, 16384, dtype=np.uint8)
+    extra = [
+        (base, np.where(rng.random(16384) < 0.95, base, rng.integers(0, 4, 16384, dtype=np.uint8)).astype(np.uint8)),  # SpeedtestSemiGlobal shape
+        (base, rng.integers(0, 4, 16384, dtype=np.uint8)),                                   # unrelated
+        (base, base.copy()),                                                                 # identical
+        (base, np.roll(base, 20)),                                                           # constant offset inside the band's reach
+        (base, np.concatenate([base[:5000], base[5040:], rng.integers(0, 4, 40, dtype=np.uint8)])),    # 40-base deletion
+        (base, np.concatenate([base[:8000], rng.integers(0, 4, 100, dtype=np.uint8), base[8000:-100]])),  # 100-base insertion: X-drop
+        (np.zeros(16384, np.uint8), np.zeros(16384, np.uint8)),                              # homopolymer
+        (np.tile(np.array([0, 1, 2, 3], np.uint8), 4096), np.tile(np.array([0, 1, 2, 3], np.uint8), 4096)[::-1].copy()),
+    ]
+    s1 = np.concatenate([g1, np.stack([e[0] for e in extra])])
+    s2 = np.concatenate([g2, np.stack([e[1] for e in extra])])
+    sg_scores, sg_lens, sg_moves, sg_ends = [], [], [], []
+    tb = np.zeros((40000, 2), np.int32)
+    for k in range(s1.shape[0]):
+        res = {}
+        for v in (0, 1, 2, 3, 4):
+            sc, ln = ctypes.c_int32(), ctypes.c_size_t()
+            a, b = np.ascontiguousarray(s1[k]), np.ascontiguousarray(s2[k])
+            assert ref.swref_semiglobal(v, P(a, u8p), P(b, u8p), ctypes.byref(sc), P(tb, i32p), ctypes.c_size_t(40000), ctypes.byref(ln)) == 0
+            res[v] = (sc.value, tb[: ln.value].copy())
+        for v in (1, 2, 3, 4):
+            assert res[v][0] == res[0][0] and np.array_equal(res[v][1], res[0][1]), ("semi-global variant %d disagrees" % v, k)
+        path = res[0][1]
+        assert tuple(path[0]) == (0, 0)
+        d = np.diff(path, axis=0)
+        moves = np.where((d[:, 0] == 1) & (d[:, 1] == 1), 1, np.where(d[:, 0] == 1, 2, 3)).astype(np.uint8)
+        assert ((d == [1, 1]).all(1) | (d == [1, 0]).all(1) | (d == [0, 1]).all(1)).all()
+        sg_scores.append(res[0][0]); sg_lens.append(len(path)); sg_moves.append(moves); sg_ends.append(path[-1])
+    np.savez_compressed(os.path.join(HERE, "f6_semiglobal.npz"), seq1=s1, seq2=s2, scores=np.array(sg_scores, np.int32),
+                        lengths=np.array(sg_lens, np.int32), ends=np.array(sg_ends, np.int32),
+                        moves=np.concatenate(sg_moves), move_offsets=np.cumsum([0] + [len(m) for m in sg_moves]).astype(np.int64))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

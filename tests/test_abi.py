@@ -21,7 +21,8 @@ def test_header_declares_the_expected_surface():
                  "swmi_score_batch_device", "swmi_score_one_vs_many", "swmi_score_one_vs_many_device", "swmi_score_batch_packed", "swmi_unpack",
                  "swmi_queue_create", "swmi_queue_submit", "swmi_queue_wait", "swmi_queue_destroy",
                  "swmi_set_schedule", "swmi_generate_pairs_device", "swmi_generate_pairs_host",
-                 "swmi_time_batch_device", "swmi_get_device_info"):
+                 "swmi_time_batch_device", "swmi_get_device_info", "swmi_score_banded_affine",
+                 "swmi_score_banded_affine_device", "swmi_semiglobal_xdrop", "swmi_semiglobal_xdrop_device"):
         assert must in syms
 
 

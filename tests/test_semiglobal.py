@@ -1,0 +1,80 @@
+"""the reference's semi-global adaptive-band X-drop aligner
+(SemiGlobal_AdaptiveBanded_XDrop_111_32_70, source.cpp:1836-1976, and its four SIMD variants :1978-2725).
+
+Fixture F6 holds inputs and the (score, traceback) the REAL reference returned -- scalar and all four SIMD variants
+agreeing, the reference's own TestSemiGlobal criterion (source.cpp:2774-2784).  The CPU oracle (oracle/sg_oracle.c) is
+pinned to it here; the GPU path is compared with both, position by position."""
+import numpy as np
+import pytest
+
+
+def _paths_from_fixture(f):
+    step = {1: (1, 1), 2: (1, 0), 3: (0, 1)}
+    out = []
+    for k in range(len(f["scores"])):
+        moves = f["moves"][f["move_offsets"][k]: f["move_offsets"][k + 1]]
+        d = np.array([step[int(m)] for m in moves], np.int32).reshape(-1, 2)
+        out.append(np.concatenate([np.zeros((1, 2), np.int32), np.cumsum(d, axis=0, dtype=np.int32)]))
+    return out
+
+
+def test_oracle_reproduces_the_reference_results(oracle, golden):
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    for k in range(len(f["scores"])):
+        score, tb = oracle.semiglobal(f["seq1"][k], f["seq2"][k])
+        assert score == int(f["scores"][k]), k
+        assert len(tb) == int(f["lengths"][k]) and np.array_equal(tb, paths[k]), k
+        assert tuple(tb[-1]) == tuple(f["ends"][k])
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden):
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    scores, tbs, lengths = gpu.semiglobal_xdrop(f["seq1"], f["seq2"])
+    assert np.array_equal(scores, f["scores"])
+    assert np.array_equal(lengths.astype(np.int64), f["lengths"].astype(np.int64))
+    for k in range(len(paths)):
+        assert np.array_equal(tbs[k], paths[k]), "traceback of case %d differs" % k
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle):
+    rng = np.random.default_rng(77)
+    n = 21                                       # odd: the last wavefront holds one alignment only
+    a = rng.integers(0, 4, (n, 16384), dtype=np.uint8)
+    b = np.zeros_like(a)
+    for k in range(n):                           # indel-rich relatives at different divergence (TestSemiGlobal's recipe)
+        p_sub, p_ins, p_del = [(0.10, 0.10, 0.10), (0.02, 0.01, 0.01), (0.2, 0.05, 0.05), (0.0, 0.0, 0.0)][k % 4]
+        out, i = [], 0
+        while len(out) < 16384:
+            r = rng.random()
+            if i >= 16384 or r < p_ins:
+                out.append(rng.integers(0, 4))
+            elif r < p_ins + p_del:
+                i += 1
+            elif r < p_ins + p_del + p_sub:
+                out.append(rng.integers(0, 4)); i += 1
+            else:
+                out.append(a[k, i]); i += 1
+        b[k] = out
+    b[5] = rng.integers(0, 4, 16384, dtype=np.uint8)            # unrelated: the X-drop rule ends the sweep early or late
+    b[6] = np.concatenate([a[6, 300:], rng.integers(0, 4, 300, dtype=np.uint8)])   # offset far beyond the band
+    scores, tbs, lengths = gpu.semiglobal_xdrop(a, b)
+    for k in range(n):
+        want_score, want_tb = oracle.semiglobal(a[k], b[k])
+        assert int(scores[k]) == want_score, k
+        assert int(lengths[k]) == len(want_tb) and np.array_equal(tbs[k], want_tb), k
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle):
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 4, (2, 16384), dtype=np.uint8)
+    b = a.copy()
+    scores, tbs, lengths = gpu.semiglobal_xdrop(a, b, cap=100)
+    assert list(scores) == [16384, 16384] and list(lengths) == [16385, 16385]
+    assert np.array_equal(tbs[0], np.stack([np.arange(100), np.arange(100)], axis=1))   # the first 100 steps of the diagonal
+    s0, t0, l0 = gpu.semiglobal_xdrop(np.zeros((0, 16384), np.uint8), np.zeros((0, 16384), np.uint8))
+    assert s0.shape == (0,) and t0 == []
