@@ -596,20 +596,19 @@ int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, c
     int rc = check_ready();
     if (rc != SWMI_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
-    for (int it = 0; it < iters; ++it) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, st);
+    for (int it = 0; he == hipSuccess && rc == SWMI_OK && it < iters; ++it)
         rc = device_entry(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, st, false);
-        if (rc != SWMI_OK) break;
-    }
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
+    if (he == hipSuccess) he = hipEventRecord(e1, st);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_time_batch_device: %s", hipGetErrorString(he));
     if (rc != SWMI_OK) return rc;
     *avg_ms = ms / float(iters);
     return SWMI_OK;
