@@ -178,7 +178,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     """Secondary row: the reference's semi-global adaptive-band X-drop aligner incl. traceback (single GPU).
     Inputs follow SpeedtestSemiGlobal (source.cpp:2805-2813): a random 16384-mer and a copy with 5 % substitutions."""
     L = 16384
-    P = args.pairs if args.pairs != (1 << 20) else 4096
+    P = args.pairs if args.pairs != (1 << 20) else 65536
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream()
     g = torch.Generator(device=dev); g.manual_seed(args.seed)

@@ -14,12 +14,19 @@
 //     positions in ascending order, as the reference returns them).
 #include "swmi_internal.h"
 
+#include <cstdlib>
+
 namespace swmi {
 namespace {
 
 constexpr int kLen = 16384;                 // std::array<uint8_t,16384>, source.cpp:1837-1838
 constexpr int kXDrop = 70;                  // X_THRESHOLD, source.cpp:1848
 constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
+// per-alignment row strides of the sweep's records, padded so that every alignment starts on a 64-byte line
+constexpr int kCodeStride = (kMaxRound + 7) & ~7;        // uint2 entries (8 B): 262208 B per alignment
+constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 65600 B per alignment
+constexpr size_t kLaneSweepMinBatch = 32768;
+constexpr size_t kLaneTracebackMinBatch = 32768; // from here on the lane-per-alignment sweep wins
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
 __device__ __forceinline__ int row16_max(int v)
@@ -64,8 +71,8 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     const bool real = a < n;
     if (!real) a = n - 1;                                 // odd tail: shadow the last alignment, store nothing
     const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
-    uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kMaxRound;
-    uint16_t *my_top = top_y + (size_t)a * kMaxRound;
+    uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kCodeStride;
+    uint16_t *my_top = top_y + (size_t)a * kTopStride;
     const int not_first = keep_opaque(k == 0 ? 0 : -1), not_last = keep_opaque(k == 31 ? 0 : -1);
     const bool writer = real && k == 0;
 
@@ -133,6 +140,176 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     if (writer) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
 }
 
+// ---- sweep, one LANE per alignment (large batches) -----------------------------------------------------------
+//
+// Same results as sg_forward_kernel, different mapping: every lane sweeps its own alignment with the 32 band cells in
+// registers, so a round needs no cross-lane instruction at all and a wavefront advances 64 alignments per ~16
+// instructions per cell (the band-per-half-wave kernel above spends ~117 instructions per round on two alignments, most
+// of them cross-lane plumbing).  It needs >= 64 alignments per wavefront to pay, i.e. large batches; the launcher picks.
+//   * dropped cells hold kNeg instead of 0: the != 0 guards of source.cpp:1922-1924 then fall out of max3, and the
+//     X-drop test "v < max(best - 70, 1)" resets every dropped cell to exactly kNeg each round;
+//   * the sequences ride along as two 64-bit windows of 2-bit fields (cell k <-> field k), shifted by one field per
+//     move; one XOR gives the match/mismatch field of all 32 cells;
+//   * the band maximum and the lane that holds it come from one max over keys (value << 5 | lane);
+//   * predecessor codes are collected as three 32-bit words per round (vd == v, vd == v || vu != v, live).
+constexpr int kNeg = -(1 << 24);
+
+__global__ void __launch_bounds__(64)
+sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
+                       uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
+{
+    // Per-lane records are staged in LDS and leave as whole 64-byte lines: every 8 rounds (codes) / 32 rounds (band rows)
+    // the wavefront writes, per instruction, the lines of 16 alignments (4 lanes x 16 B each).  Storing 8 + 2 bytes per
+    // lane per round directly would issue 128 partial-line requests per round and leave the sweep waiting on the TA.
+    __shared__ uint2 stage_codes[64][8];                  // [alignment of the block][round & 7]
+    __shared__ uint16_t stage_top[64][32];                // [alignment of the block][round & 31]
+    const int lane = threadIdx.x;
+    const uint32_t block_first = blockIdx.x * 64;
+    const uint32_t a0 = block_first + threadIdx.x;
+    const bool real = a0 < n;
+    const uint32_t a = real ? a0 : n - 1;
+    const uint8_t *s1 = seq1s + (size_t)a * kLen;
+    const uint8_t *s2 = seq2s + (size_t)a * kLen;
+    // group-of-8-rounds `g8` (rounds 8*g8 .. 8*g8+7) of all 64 alignments -> global, 4 x 16 lines
+    auto flush_codes = [&](int g8) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int al = q * 16 + (lane >> 2), part = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[al][2 * part]);
+            if (block_first + al < n)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + al) * kCodeStride + 8 * g8 + 2 * part) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_top = [&](int g32) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int al = q * 16 + (lane >> 2), part = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_top[al][8 * part]);
+            if (block_first + al < n)
+                *reinterpret_cast<uint4 *>(top_y + (size_t)(block_first + al) * kTopStride + 32 * g32 + 8 * part) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int cur[32], hor[32], ver[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { cur[k] = kNeg; hor[k] = kNeg; ver[k] = kNeg; }
+    cur[31] = kXDrop;
+    // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
+    unsigned long long aw = 0, av = 0, bw = 0, bv = 0;
+#pragma unroll
+    for (int k = 0; k <= 30; ++k) {
+        aw |= (unsigned long long)(s1[30 - k] & 3u) << (2 * k);
+        av |= 3ull << (2 * k);
+    }
+    int pos_x = 31;
+    int best = kXDrop, best_round = 0, best_lane = 31, rounds = 1, last_round = 0;
+    bool alive = true;
+    stage_codes[lane][0] = make_uint2(0, 0);
+    stage_top[lane][0] = 0;
+    // sequence characters arrive 16 at a time, one 16-byte load per lane per 16 consumed characters, fetched one
+    // buffer ahead (the load has 16 moves to land)
+    uint4 abuf = *reinterpret_cast<const uint4 *>(s1 + 16);    // seq1[16..31]: the next step down consumes seq1[31]
+    uint4 anext = *reinterpret_cast<const uint4 *>(s1 + 32);
+    uint4 bbuf = *reinterpret_cast<const uint4 *>(s2);         // seq2[0..15]:  the next step right consumes seq2[0]
+    uint4 bnext = *reinterpret_cast<const uint4 *>(s2 + 16);
+    auto pick = [](const uint4 &buf, int idx) -> unsigned {    // character idx & 15 of the buffered 16
+        const unsigned w = (idx & 8) ? ((idx & 4) ? buf.w : buf.z) : ((idx & 4) ? buf.y : buf.x);
+        return (w >> (8 * (idx & 3))) & 3u;
+    };
+
+    for (int round = 1; round < kMaxRound; ++round) {
+        if (!__any(alive)) break;
+        const bool right = cur[0] < cur[31];              // source.cpp:1895
+        pos_x += right ? 1 : 0;
+        const int pos_y = round - (pos_x - 31);
+        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
+        // sequence windows follow the band
+        {
+            const int ia = pos_y + 30, ib = pos_x - 32;   // 0-based index of the character that has just entered
+            const bool va = (unsigned)ia < (unsigned)kLen, vb = (unsigned)ib < (unsigned)kLen;
+            const unsigned cand_a = pick(abuf, ia), cand_b = pick(bbuf, ib);
+            const unsigned long long aw_d = (aw << 2) | cand_a, av_d = (av << 2) | (va ? 3ull : 0ull);
+            const unsigned long long bw_r = (bw >> 2) | ((unsigned long long)cand_b << 62), bv_r = (bv >> 2) | (vb ? 3ull << 62 : 0ull);
+            aw = right ? aw : aw_d;  av = right ? av : av_d;
+            bw = right ? bw_r : bw;  bv = right ? bv_r : bv;
+            // a buffer whose last character (index 15 mod 16) has just been consumed is replaced by the prefetched one
+            if (!right && (ia & 15) == 15) {
+                abuf = anext;
+                if (ia + 17 < kLen) anext = *reinterpret_cast<const uint4 *>(s1 + ia + 17);
+            }
+            if (right && (ib & 15) == 15) {
+                bbuf = bnext;
+                if (ib + 17 < kLen) bnext = *reinterpret_cast<const uint4 *>(s2 + ib + 17);
+            }
+        }
+        const unsigned long long x = aw ^ bw;
+        const unsigned long long same = ~(x | (x >> 1)) & 0x5555555555555555ull & av & bv;   // bit 2k: cell k is a match
+        const unsigned long long m2 = same << 1;                                            // field k = 2 (match) or 0
+        const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32);
+
+        int kmax = kNeg;
+        unsigned wd = 0, wx = 0;
+        int pending = 0;                                  // new value of cell k+1, written once cell k no longer needs the old one
+#pragma unroll
+        for (int k = 31; k >= 0; --k) {
+            const int c_lo = k > 0 ? cur[k - 1] : kNeg, c_mid = cur[k], c_hi = k < 31 ? cur[k + 1] : kNeg;
+            const int dia = right ? ver[k] : hor[k];      // :1897 / :1908
+            const int nh = right ? c_mid : c_lo;          // :1898 / :1910-1911
+            const int nv = right ? c_hi : c_mid;          // :1899-1900 / :1909
+            hor[k] = nh;
+            ver[k] = nv;
+            const int f = (int)(((k < 16 ? m2lo : m2hi) >> (2 * (k & 15))) & 3u);
+            const int vd = dia + f - 1;                   // +1 / -1, :1918-1922
+            const int vu = nv - 1, vl = nh - 1;           // :1923-1924
+            const int m1 = vd > vu ? vd : vu;
+            const int v0 = m1 > vl ? m1 : vl;
+            const int key = (int)(((unsigned)v0 << 5) | (unsigned)k);
+            kmax = kmax > key ? kmax : key;
+            const bool is_d = vd == v0, is_u = vu == v0;
+            wd = (wd << 1) | (is_d ? 1u : 0u);
+            wx = (wx << 1) | ((is_d || !is_u) ? 1u : 0u);
+            if (k < 31) cur[k + 1] = pending;
+            pending = v0;
+        }
+        cur[0] = pending;
+        const int band_best = kmax >> 5;                  // arithmetic shift: the value part of the winning key
+        const int round_best = band_best > 0 ? band_best : 0;
+        const bool improved = alive && round_best > best; // :1933-1936
+        best = improved ? round_best : best;
+        best_round = improved ? round : best_round;
+        best_lane = improved ? (kmax & 31) : best_lane;   // highest lane among equals: where the search of :1957 stops
+        const int thr = best - kXDrop > 1 ? best - kXDrop : 1;                // :1938-1941, and "0 means dropped"
+        unsigned nz = 0;
+#pragma unroll
+        for (int k = 31; k >= 0; --k) {
+            const bool live = cur[k] >= thr;
+            cur[k] = live ? cur[k] : kNeg;
+            nz = (nz << 1) | (live ? 1u : 0u);
+        }
+        // codes 1 / 2 / 3 = diag / up / left (:1962-1971).  Rounds past a lane's end are staged and flushed too: they
+        // land beyond `rounds` of that alignment, which the traceback never reads.
+        stage_codes[lane][round & 7] = make_uint2(nz & wx, nz & ~wd);
+        stage_top[lane][round & 31] = (uint16_t)pos_y;
+        if ((round & 7) == 7) flush_codes(round >> 3);
+        if ((round & 31) == 31) flush_top(round >> 5);
+        rounds = alive ? round + 1 : rounds;
+        alive = alive && round_best != 0;                 // :1943-1946
+        last_round = round;
+    }
+    // the partial groups of the last executed round (uniform across the wavefront)
+    if ((last_round & 7) != 7) flush_codes(last_round >> 3);
+    if ((last_round & 31) != 31) flush_top(last_round >> 5);
+    if (real) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
+}
+
 // Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
 // 64 consecutive rounds of (code words, band row) each, fetched with coalesced loads one block ahead of the walker, and
 // the walker picks its round with v_readlane.  Two walks: the first counts the steps, the second writes the positions
@@ -144,8 +321,8 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
 {
     const uint32_t a = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kMaxRound;
-    const uint16_t *my_top = top_y + (size_t)a * kMaxRound;
+    const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride;
+    const uint16_t *my_top = top_y + (size_t)a * kTopStride;
     const int4 sum = summary[a];
     const int y0 = (int)my_top[sum.y] + 31 - sum.z;
     const int x0 = sum.y - y0;
@@ -215,12 +392,71 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     if (lane == 0) { scores[a] = sum.x; lengths[a] = total; }
 }
 
+// Traceback, one LANE per alignment (large batches): the wave-per-alignment walker above is bound by the scalar unit
+// (one walk per wavefront, ~40 scalar instructions per step); here 64 walks advance per vector instruction.  Each lane
+// keeps the 64-byte line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS and refills it
+// from global memory when the walk leaves it; two walks (count, then write each position at its final index).
+__global__ void __launch_bounds__(64)
+sg_traceback_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
+                         const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
+                         uint32_t cap, uint32_t *__restrict__ lengths)
+{
+    __shared__ uint4 line_codes[64][4 + 1];               // [lane][16-byte quarter of the line], padded
+    __shared__ uint4 line_top[64][4 + 1];
+    const int lane = threadIdx.x;
+    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= n) return;                                   // no wave-level synchronisation below: lanes are independent
+    const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
+    const uint4 *my_top = reinterpret_cast<const uint4 *>(top_y + (size_t)a * kTopStride);
+    const int4 sum = summary[a];
+    const int y0 = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
+    const int x0 = sum.y - y0;
+    int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
+
+    uint32_t total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int y = y0, x = x0;
+        int have_codes = -1, have_top = -1;               // line numbers currently staged
+        uint32_t count = 1;
+        uint32_t idx = total - 1;                         // pass 1: index of the current position in the ascending list
+        if (pass == 1 && idx < cap) out[idx] = make_int2(y, x);
+        while ((y | x) != 0) {
+            const int r = y + x;
+            if ((r >> 3) != have_codes) {
+                have_codes = r >> 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) line_codes[lane][q] = my_codes[4 * have_codes + q];
+            }
+            if ((r >> 5) != have_top) {
+                have_top = r >> 5;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) line_top[lane][q] = my_top[4 * have_top + q];
+            }
+            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
+            const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
+            const int bl = 31 - (y - top);
+            const int code = (int)((cw.x >> bl) & 1u) | (int)(((cw.y >> bl) & 1u) << 1);
+            if (code == 0) break;                         // cannot happen for a cell on a live path
+            y -= (code != 3) ? 1 : 0;                     // 1 diag, 2 up: one row back
+            x -= (code != 2) ? 1 : 0;                     // 1 diag, 3 left: one column back
+            ++count;
+            if (pass == 1) {
+                --idx;
+                if (idx < cap) out[idx] = make_int2(y, x);
+            }
+        }
+        total = count;
+    }
+    scores[a] = sum.x;
+    lengths[a] = total;
+}
+
 }  // namespace
 
 namespace {
 inline size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
-inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kMaxRound * 2 * sizeof(uint32_t)); }
-inline size_t top_bytes(size_t n) { return round16(n * (size_t)kMaxRound * sizeof(uint16_t)); }
+inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeStride * sizeof(uint2)); }
+inline size_t top_bytes(size_t n) { return round16(n * (size_t)kTopStride * sizeof(uint16_t)); }
 }  // namespace
 
 size_t semiglobal_workspace_bytes(size_t n)
@@ -238,13 +474,28 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + top_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
-    const unsigned waves = (unsigned)((n + 1) / 2);
-    hipLaunchKernelGGL(sg_forward_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes,
-                       top, summary);
+    // two mappings of the sweep, same results: a band per half-wavefront (low latency, fills the chip from a few
+    // thousand alignments) or an alignment per lane (far fewer instructions per alignment, needs a large batch)
+    const char *force = getenv("SWMI_SG_SWEEP");
+    const bool lane_sweep = force ? atoi(force) == 1 : n >= kLaneSweepMinBatch;
+    if (lane_sweep) {
+        hipLaunchKernelGGL(sg_forward_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_seq1s, d_seq2s,
+                           (uint32_t)n, codes, top, summary);
+    } else {
+        const unsigned waves = (unsigned)((n + 1) / 2);
+        hipLaunchKernelGGL(sg_forward_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes,
+                           top, summary);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sg_traceback_kernel, dim3((unsigned)n), dim3(64), 0, stream, (uint32_t)n, codes, top, summary, d_scores,
-                       d_tracebacks, (uint32_t)cap, d_lengths);
+    const char *force_tb = getenv("SWMI_SG_TRACEBACK");
+    const bool lane_tb = force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;
+    if (lane_tb)
+        hipLaunchKernelGGL(sg_traceback_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
+                           summary, d_scores, d_tracebacks, (uint32_t)cap, d_lengths);
+    else
+        hipLaunchKernelGGL(sg_traceback_kernel, dim3((unsigned)n), dim3(64), 0, stream, (uint32_t)n, codes, top, summary, d_scores,
+                           d_tracebacks, (uint32_t)cap, d_lengths);
     return hipGetLastError();
 }
 

@@ -28,8 +28,20 @@ def test_oracle_reproduces_the_reference_results(oracle, golden):
         assert tuple(tb[-1]) == tuple(f["ends"][k])
 
 
+@pytest.fixture
+def sg_kernels(monkeypatch):
+    """Select the sweep / traceback mapping (0 = band per half-wavefront + wave-per-alignment walker, the small-batch
+    pair; 1 = lane per alignment, the large-batch pair).  The library reads the variables at every launch."""
+    def choose(sweep, traceback):
+        monkeypatch.setenv("SWMI_SG_SWEEP", str(sweep))
+        monkeypatch.setenv("SWMI_SG_TRACEBACK", str(traceback))
+    return choose
+
+
 @pytest.mark.gpu
-def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden):
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1), (0, 1), (1, 0)])
+def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep, traceback):
+    sg_kernels(sweep, traceback)
     f = golden("f6_semiglobal")
     paths = _paths_from_fixture(f)
     scores, tbs, lengths = gpu.semiglobal_xdrop(f["seq1"], f["seq2"])
@@ -40,9 +52,11 @@ def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden):
 
 
 @pytest.mark.gpu
-def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle):
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1)])
+def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, sweep, traceback):
+    sg_kernels(sweep, traceback)
     rng = np.random.default_rng(77)
-    n = 21                                       # odd: the last wavefront holds one alignment only
+    n = 21 if sweep == 0 else 70                 # odd / not a multiple of 64: ragged last wavefront
     a = rng.integers(0, 4, (n, 16384), dtype=np.uint8)
     b = np.zeros_like(a)
     for k in range(n):                           # indel-rich relatives at different divergence (TestSemiGlobal's recipe)
@@ -69,7 +83,9 @@ def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle):
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1)])
+def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep, traceback):
+    sg_kernels(sweep, traceback)
     rng = np.random.default_rng(4)
     a = rng.integers(0, 4, (2, 16384), dtype=np.uint8)
     b = a.copy()
