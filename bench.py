@@ -322,6 +322,12 @@ def main():
                 w.wait()
         torch.cuda.synchronize()
 
+    # settle the clocks first: after idle the first ~10 launches run 10 % slower (DVFS ramp, profiles/r01c kernel trace);
+    # this is extra untimed work on top of the W warmup steps the caller asked for, so that a small W still measures
+    # the steady state
+    for k in range(40):
+        step(k)
+    drain()
     for k in range(args.warmup):
         step(k)
     drain()
