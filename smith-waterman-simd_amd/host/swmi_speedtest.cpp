@@ -83,6 +83,23 @@ int main(int argc, char **argv)
             printf("mi355x batch version: %.1f ms / %.0fM distinct pairs incl. PCIe  (%.1f M alignments/s, checksum %lld)\n", ms,
                    n / 1e6, n / ms / 1e3, sum);
         }
+        {   // the same pairs in the reference's 2-bit wire format (unpack(), source.cpp:1580-1583): a quarter of the PCIe bytes
+            std::vector<uint8_t> s1(n * 128), s2(n * 128), p1(n * 32), p2(n * 32);
+            std::vector<int32_t> out(n);
+            swmi_generate_pairs_host(s1.data(), s2.data(), n, 10000, 0);
+            for (size_t i = 0; i < n * 32; ++i) {
+                p1[i] = uint8_t(s1[4 * i] | (s1[4 * i + 1] << 2) | (s1[4 * i + 2] << 4) | (s1[4 * i + 3] << 6));
+                p2[i] = uint8_t(s2[4 * i] | (s2[4 * i + 1] << 2) | (s2[4 * i + 2] << 4) | (s2[4 * i + 3] << 6));
+            }
+            if (swmi_score_batch_packed(p1.data(), p2.data(), n, sm.data(), gap, out.data()) != SWMI_OK) die("swmi_score_batch_packed");
+            const double t0 = now_ms();
+            if (swmi_score_batch_packed(p1.data(), p2.data(), n, sm.data(), gap, out.data()) != SWMI_OK) die("swmi_score_batch_packed");
+            const double ms = now_ms() - t0;
+            long long sum = 0;
+            for (int32_t s : out) sum += s;
+            printf("mi355x packed batch version: %.1f ms / %.0fM distinct pairs incl. PCIe  (%.1f M alignments/s, checksum %lld)\n", ms,
+                   n / 1e6, n / ms / 1e3, sum);
+        }
         {
             void *d1 = nullptr, *d2 = nullptr, *ds = nullptr;
             if (hipMalloc(&d1, n * 128) != hipSuccess || hipMalloc(&d2, n * 128) != hipSuccess ||
