@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Long-running differential fuzz of the GPU scorer against the CPU oracle (and the real reference where present) --
+the reference's own TestSimdSmithWaterman idea (source.cpp:2943-2982: fresh random pairs until bored), at GPU scale.
+
+    python tools/fuzz_parity.py --seconds 240            # on the GPU box; writes a summary line per parameter set
+
+Every round generates a fresh batch on the device (counter-based generator, new seed), scores it through the C ABI,
+copies the inputs back and scores them with oracle/liboracle.so on all host cores (OpenMP); any mismatch is dumped.
+A second phase does the same for the semi-global aligner against the reference's simd_mark4 (full tracebacks)."""
+import argparse, ctypes, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "smith-waterman-simd_amd"))
+import swmi, torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120)
+ap.add_argument("--batch", type=int, default=1 << 22)
+ap.add_argument("--sg-seconds", type=float, default=60)
+args = ap.parse_args()
+swmi.init(0)
+vp = ctypes.c_void_p
+orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+rng = np.random.default_rng(int(time.time()))
+n = args.batch
+d1 = torch.empty(n * 128, dtype=torch.uint8, device="cuda"); d2 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+out = torch.empty(n, dtype=torch.int32, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+t_end = time.time() + args.seconds
+total = mism = rounds = 0
+while time.time() < t_end:
+    seed = int(rng.integers(0, 2**62)); first = int(rng.integers(0, 2**40))
+    kind = rounds % 4
+    if kind == 0: sm = swmi.match_matrix(10, -30); gap = 15
+    elif kind == 1: sm = swmi.match_matrix(1, -1); gap = 1
+    elif kind == 2: sm = rng.integers(-128, 128, 16).astype(np.int8); gap = int(rng.integers(0, 128))
+    else: sm = rng.integers(-12, 13, 16).astype(np.int8); gap = int(rng.integers(0, 9))
+    L = [4, 8, 16, 2, 32, 64][rounds % 6]
+    swmi.set_schedule(L, int(rng.integers(0, 2)))
+    swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, seed, first, st)
+    if rounds % 3 == 1:      # make half of the batch related pairs (mutated copies) so that long alignments occur
+        m = torch.rand(n * 128, device="cuda") < 0.85
+        half = (n // 2) * 128
+        d2[:half] = torch.where(m[:half], d1[:half], d2[:half])
+    swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, gap, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    a = d1.cpu().numpy(); b = d2.cpu().numpy(); got = out.cpu().numpy()
+    want = np.zeros(n, np.int32)
+    orc.sw_oracle_batch(a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.c_size_t(n), sm.ctypes.data_as(vp), gap, want.ctypes.data_as(vp))
+    bad = int((got != want).sum())
+    total += n; mism += bad; rounds += 1
+    if bad:
+        i = int(np.nonzero(got != want)[0][0])
+        print("MISMATCH seed %d first %d L %d gap %d sm %s: pair %d got %d want %d (%d bad)" % (seed, first, L, gap, sm.tolist(), i, got[i], want[i], bad), flush=True)
+    if rounds % 10 == 0:
+        print("... %d rounds, %.0f M pairs, %d mismatches" % (rounds, total / 1e6, mism), flush=True)
+print("SW128 fuzz: %d rounds, %d pairs, %d mismatches (all six schedules, folded and general cell, four parameter families)" % (rounds, total, mism), flush=True)
+
+# ---- semi-global aligner against the real reference (if present) or the oracle --------------------------------------
+ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
+ref = ctypes.CDLL(ref_path) if os.path.exists(ref_path) else None
+t_end = time.time() + args.sg_seconds
+sg_total = sg_bad = 0
+workers = min(64, os.cpu_count() or 8)
+def check(arg):
+    a, b, score, tb = arg
+    buf = np.zeros((32769, 2), np.int32); sc = ctypes.c_int32(); ln = ctypes.c_size_t()
+    if ref is not None:
+        ref.swref_semiglobal(4, a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.byref(sc), buf.ctypes.data_as(vp), ctypes.c_size_t(32769), ctypes.byref(ln))
+    else:
+        oob = ctypes.c_int()
+        orc.sg_oracle_xdrop(a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.byref(sc), buf.ctypes.data_as(vp), ctypes.c_size_t(32769), ctypes.byref(ln), ctypes.byref(oob))
+    return sc.value == score and ln.value == len(tb) and np.array_equal(buf[: ln.value], tb)
+while time.time() < t_end:
+    m = 2048
+    a = rng.integers(0, 4, (m, 16384), dtype=np.uint8)
+    p = rng.random((m, 1)) * 0.3
+    b = np.where(rng.random((m, 16384)) < p, rng.integers(0, 4, (m, 16384), dtype=np.uint8), a).astype(np.uint8)
+    for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
+        cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
+        b[k, cut:] = np.roll(b[k], sh)[cut:]
+    os.environ["SWMI_SG_SWEEP"] = str(sg_total // m % 2); os.environ["SWMI_SG_TRACEBACK"] = str(sg_total // m % 2)
+    scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
+    with ThreadPoolExecutor(workers) as ex:
+        ok = list(ex.map(check, [(a[k], b[k], int(scores[k]), tbs[k]) for k in range(m)]))
+    sg_total += m; sg_bad += m - sum(ok)
+    print("... semi-global %d alignments, %d mismatches" % (sg_total, sg_bad), flush=True)
+print("semi-global fuzz vs %s: %d alignments (score + full traceback), %d mismatches" % ("reference simd_mark4" if ref else "oracle", sg_total, sg_bad), flush=True)
