@@ -256,7 +256,7 @@ sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32);
 
         int kmax = kNeg;
-        unsigned wd = 0, wx = 0;
+        unsigned w_nd = 0, w_nu = 0;                      // bit k: vd != v0 / vu != v0, shifted in as the sign of the difference
         int pending = 0;                                  // new value of cell k+1, written once cell k no longer needs the old one
 #pragma unroll
         for (int k = 31; k >= 0; --k) {
@@ -273,9 +273,8 @@ sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
             const int v0 = m1 > vl ? m1 : vl;
             const int key = (int)(((unsigned)v0 << 5) | (unsigned)k);
             kmax = kmax > key ? kmax : key;
-            const bool is_d = vd == v0, is_u = vu == v0;
-            wd = (wd << 1) | (is_d ? 1u : 0u);
-            wx = (wx << 1) | ((is_d || !is_u) ? 1u : 0u);
+            w_nd = __builtin_amdgcn_alignbit(w_nd, (unsigned)(vd - v0), 31);   // (w << 1) | sign(vd - v0); v0 >= vd always
+            w_nu = __builtin_amdgcn_alignbit(w_nu, (unsigned)(vu - v0), 31);
             if (k < 31) cur[k + 1] = pending;
             pending = v0;
         }
@@ -287,13 +286,14 @@ sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         best_round = improved ? round : best_round;
         best_lane = improved ? (kmax & 31) : best_lane;   // highest lane among equals: where the search of :1957 stops
         const int thr = best - kXDrop > 1 ? best - kXDrop : 1;                // :1938-1941, and "0 means dropped"
-        unsigned nz = 0;
+        unsigned w_drop = 0;
 #pragma unroll
         for (int k = 31; k >= 0; --k) {
-            const bool live = cur[k] >= thr;
-            cur[k] = live ? cur[k] : kNeg;
-            nz = (nz << 1) | (live ? 1u : 0u);
+            const int d = cur[k] - thr;
+            w_drop = __builtin_amdgcn_alignbit(w_drop, (unsigned)d, 31);
+            cur[k] = d < 0 ? kNeg : cur[k];
         }
+        const unsigned nz = ~w_drop, wd = ~w_nd, wx = ~w_nd | w_nu;   // live; came by the diagonal; diagonal or not up
         // codes 1 / 2 / 3 = diag / up / left (:1962-1971).  Rounds past a lane's end are staged and flushed too: they
         // land beyond `rounds` of that alignment, which the traceback never reads.
         stage_codes[lane][round & 7] = make_uint2(nz & wx, nz & ~wd);
