@@ -166,6 +166,17 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
     using profile_t = std::conditional_t<kWideProfile, uint32_t, uint16_t>;
     __shared__ profile_t lds_profile[kWavesPerBlock][A * S];
     __shared__ uint32_t lds_rows[kWavesPerBlock][4];          // score-matrix rows, per wave
+    // Part of the running maximum is kept by the LDS unit: rows with (i % kBestDen) < kBestNum send their value to a
+    // per-lane LDS word with ds_max_i32 (no return value, wavefront scope) instead of spending VALU issue cycles on it.
+    // The LDS pipe is otherwise idle in this kernel; one such atomic costs it ~4.3 cycles per wavefront, so about half
+    // of the rows is what it can absorb before it becomes the bottleneck itself.
+#ifndef SWMI_LDS_BEST_NUM
+#define SWMI_LDS_BEST_NUM (R >= 64 ? 0 : R >= 32 ? 1 : R >= 16 ? 2 : R >= 8 ? 1 : 0)   // measured per L, 1M pairs
+#define SWMI_LDS_BEST_DEN (R >= 64 ? 1 : R >= 32 ? 2 : R >= 16 ? 3 : R >= 8 ? 2 : 1)
+#endif
+    constexpr int kBestNum = I16 ? 0 : SWMI_LDS_BEST_NUM, kBestDen = SWMI_LDS_BEST_DEN;
+    __shared__ int lds_best[kWavesPerBlock][64];
+    lds_best[threadIdx.x >> 6][threadIdx.x & 63] = 0;         // own word, read back by the same lane: no barrier needed
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -251,7 +262,9 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
             if constexpr (FOLD) {
                 const int lu = left > up ? left : up;
                 const int x = lu > tsum ? lu : tsum;                        // v_max3_i32 (half rate, two maxes)
-                best = I16 ? keep(max_i16(best, x)) : vmax<false>(best, x);
+                if constexpr (I16) best = keep(max_i16(best, x));
+                else if (i % kBestDen < kBestNum) __hip_atomic_fetch_max(&lds_best[wv][lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                else best = vmax<false>(best, x);
                 hn = sat_sub<I16>(x, gap);
                 up = hn;
             } else if constexpr (I16) {
@@ -263,7 +276,8 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
                 const int gl = hg[i];
                 const int lu = gl > up ? gl : up;
                 hn = lu > tsum ? lu : tsum;                                 // v_max3_i32; >= 0 because gl >= 0
-                best = vmax<false>(best, hn);
+                if (i % kBestDen < kBestNum) __hip_atomic_fetch_max(&lds_best[wv][lane], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                else best = vmax<false>(best, hn);
                 const int gn = sat_sub<false>(hn, gap);
                 hg[i] = gn;
                 up = gn;
@@ -284,6 +298,10 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
     }
 
     // ---- reduce over the L lanes of the group, one int32 per alignment ------------------------------
+    if constexpr (kBestNum > 0) {
+        const int from_lds = lds_best[wv][lane];
+        best = best > from_lds ? best : from_lds;
+    }
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) {
         const int other = __shfl_xor(best, o);
