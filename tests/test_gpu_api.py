@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_device_is_gfx950_and_native_library_is_loaded(gpu):
     info = gpu.device_info()
-    assert info["arch"].startswith("gfx950") and info["wavefront_size"] == 64 and info["compute_units"] == 256
+    assert info["arch"].startswith("gfx950") and info["wavefront_size"] == 64 and info["compute_units"] >= 32
     maps = open("/proc/self/maps").read()
     assert "libswmi.so" in maps
 
