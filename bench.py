@@ -377,6 +377,12 @@ def main():
                     "frac": round(P * bytes_per_alignment / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
             "gcups_kernel": round(P * CELLS / kernel_s / 1e9, 1),
         }
+        # the honest utilisation figure: VALU issue cycles the cell body needs (1 v_dot4 + 1 v_max3 + 1/4 v_max3 at 4 clk,
+        # 1 v_sub at 2 clk = 11 per wave-cell) against the cycles the launch took at the nominal clock
+        wave_cells = P * CELLS / 64.0
+        ideal_s = wave_cells * 11.0 / (256 * 4 * 2.4e9)
+        roof["issue_bound"] = {"valu_cycles_per_wave_cell": 11, "ideal_kernel_ms_at_2.4GHz": round(ideal_s * 1e3, 4),
+                               "frac": round(ideal_s / kernel_s, 4)}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
