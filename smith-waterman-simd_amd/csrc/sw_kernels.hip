@@ -4,28 +4,37 @@
 //     H(i,j) = max(0, H(i-1,j-1) + sm[seq1[i-1]*4 + seq2[j-1]], H(i-1,j) - gap, H(i,j-1) - gap)
 //     score  = max over the 128 x 128 cells
 // This is NOT a translation of the reference's AVX2 parallelogram (source.cpp:462-571). The design is
-// driven by what the gfx950 VALU issues at full rate (tools/microbench/valu_rate*.hip):
+// driven by what the gfx950 VALU issues at full / half rate (tools/microbench/*.hip):
 //
 //   * A 64-lane wavefront walks the anti-diagonals of 64/L alignments at once: L lanes per alignment,
 //     lane j of a group owns the R = 128/L consecutive rows j*R .. j*R+R-1 and, at step t, computes the
 //     R cells of column c = t - j (top to bottom).  L = 64 is literally "one wavefront per alignment";
 //     smaller L trades lanes-in-flight for a shorter pipeline fill (L-1 idle steps of 128+L-1) and fewer
-//     cross-lane moves per cell.
+//     cross-lane moves per cell.  Default L = 4.
 //   * The vertical/diagonal dependency between neighbouring lanes is one DPP lane shift per step
-//     (v_mov_b32_dpp / v_and_b32_dpp row_shr:1 or wave_shr:1 -- what __shfl_up(v,1) should be on gfx9;
+//     (v_and_b32_dpp / v_mov_b32_dpp row_shr:1 or wave_shr:1 -- what __shfl_up(v,1) should be on gfx9;
 //     the compiler lowers __shfl_up to ds_bpermute_b32, which costs an LDS round trip).
 //   * The query profile lives in LDS: for every column of seq2 a one-hot dword (1 << 8*base).  A lane reads
-//     the profile entry of its current column with one ds_read_b32 per step; out-of-range columns hit zero pads,
-//     which makes pipeline fill/drain steps harmless without any predication.
-//   * The score lookup AND the diagonal add are ONE instruction: v_dot4c_i32_i8 acc=H(i-1,j-1),
-//     a = the row's 4 int8 scores, b = the column's one-hot.
-//   * max() runs on v_max_i16 (full rate on gfx950; v_max_i32 / v_max3_i32 are half rate). All H values fit
-//     in 15 bits (<= 128*127), t = H + s fits int16.
+//     the profile entry of its current column with one ds_read_b32 per step; out-of-range columns hit zero pads.
+//   * The score lookup AND the diagonal add are ONE instruction: v_dot4_i32_i8 (acc = H(i-1,j-1), a = the row's
+//     4 int8 scores, b = the column's one-hot).
+//   * The three-way max is one v_max3_i32, "- gap, floor 0" one v_sub_u32 ... clamp; half of the running-maximum
+//     updates go to the otherwise idle LDS unit as ds_max_i32.
 //
-// Two cell bodies, identical results:
-//   general : t = dot4c(row, onehot, diag); m = max(left, up); mg = sat_sub(m, gap); h = max(mg, t)
+// Cell bodies, identical results (template flags):
 //   folded  : rows carry s + gap (host folds when every s + gap fits int8):
-//             x = max(left, up, dot4c(row', onehot, diag)); h = sat_sub(x, gap); best tracks x
+//             x = max3(left, up, dot4(row', onehot, diag)); h = x -sat gap; the maximum is tracked on x
+//   general : any int8 matrix: h = max3(gleft, gup, dot4(row, onehot, diag)); g = h -sat gap (h and g kept per row)
+//   16-bit  : v_max_i16 formulation, kept for A/B only
+//
+// Why nothing is masked during pipeline fill and drain (lane j works on column t - j, which is < 0 for the first j
+// steps and >= 128 for the last L-1-j):
+//   before the first column: every profile entry read is 0, so dot4 adds nothing; all inputs of the cell (left, up,
+//     diag) are still 0, hence x = 0 (folded) / h = 0 (general) and the state stays all-zero until column 0 arrives;
+//   after the last column: the entries are 0 again, the cell computes x = max(left, up, diag) -- every value it can
+//     produce is bounded by a value some real cell already held, which the running maximum has seen; such cells only
+//     feed cells that are themselves past the last column (a lane's neighbour j+1 is one column behind it), so neither
+//     the score nor any real cell can change.  This needs gap >= 0, which the C ABI enforces.
 #include "swmi_internal.h"
 
 #include <type_traits>
