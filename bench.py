@@ -435,6 +435,15 @@ def main():
             sample = args.cpu_sample or min(P, 1 << 20)
             line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores[0].cpu().numpy(), min(sample, P))
             line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)
+            # end-to-end through the host-buffer entry point (H2D + kernel + D2H; SURVEY 8d "reported separately"; never `value`)
+            h1, h2 = swmi.generate_pairs_host(P, args.seed, 0)
+            swmi.score_batch(h1, h2, sm, args.gap)
+            t3 = time.perf_counter()
+            hs = swmi.score_batch(h1, h2, sm, args.gap)
+            dt3 = time.perf_counter() - t3
+            line["host_buffer_path"] = {"entry": "swmi_score_batch (pageable host memory, PCIe inclusive)",
+                                        "ms": round(dt3 * 1e3, 3), "value": round(P / dt3, 1), "unit": "alignments/s",
+                                        "matches_resident_scores": bool((hs == scores[0].cpu().numpy()).all())}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
