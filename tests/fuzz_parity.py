@@ -2,7 +2,7 @@
 """Long-running differential fuzz of the GPU scorer against the CPU oracle (and the real reference where present) --
 the reference's own TestSimdSmithWaterman idea (source.cpp:2943-2982: fresh random pairs until bored), at GPU scale.
 
-    python tools/fuzz_parity.py --seconds 240            # on the GPU box; writes a summary line per parameter set
+    python tests/fuzz_parity.py --seconds 240            # on the GPU box; writes a summary line per parameter set
 
 Every round generates a fresh batch on the device (counter-based generator, new seed), scores it through the C ABI,
 copies the inputs back and scores them with oracle/liboracle.so on all host cores (OpenMP); any mismatch is dumped.
@@ -10,7 +10,7 @@ A second phase does the same for the semi-global aligner against the reference's
 import argparse, ctypes, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ lives one level below the repo root
 sys.path.insert(0, os.path.join(ROOT, "smith-waterman-simd_amd"))
 import swmi, torch
 
