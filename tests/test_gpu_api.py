@@ -118,3 +118,30 @@ def test_error_paths_on_device(gpu):
     with pytest.raises(gpu.SwmiError) as e:
         gpu.set_schedule(5, 0)
     assert e.value.code == gpu.ERR_INVALID_ARGUMENT
+
+
+def test_cpp_compat_header_and_pair_queue(gpu, golden, tmp_path):
+    """include/swmi_compat.hpp from a plain C++ program (g++, no HIP headers): the reference-shaped overload and PairQueue."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import PKG, ROOT
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    f = golden("f3_harness")
+    n = 300
+    raw = np.stack([f["seq1"][:n], f["seq2"][:n]], axis=1).astype(np.uint8)      # n x 2 x 128
+    data = tmp_path / "pairs.bin"
+    raw.tofile(str(data))
+    exe = str(tmp_path / "compat_check")
+    lib = os.path.join(PKG, "lib")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "native", "compat_check.cpp"), "-o", exe, "-L", lib, "-lswmi",
+                            "-Wl,-rpath," + lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    run = subprocess.run([exe, str(data), "10", "-30", "15"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert run.returncode == 0, run.stderr
+    rows = [tuple(map(int, line.split())) for line in run.stdout.strip().splitlines()]
+    assert len(rows) == n
+    assert [r[0] for r in rows] == list(f["scores"][0][:n])
+    assert [r[1] for r in rows] == list(f["scores"][0][:n])
