@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--gap", type=int, default=15)
     ap.add_argument("--seed", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group and run the score gather even "
+                    "with one rank (rehearses the RCCL path on a one-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto, ~10-15 s)")
@@ -286,12 +288,29 @@ def main():
     if args.lanes:
         swmi.set_schedule(args.lanes, 0)
     lanes, flags = swmi.get_schedule()
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+        if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on STDOUT when the communicator comes up; the contract is ONE JSON line there, so
+        # stdout points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     if args.mode == "banded-affine":            # BASELINE configs[4] (extension, parity unpinned by the reference)
         return bench_banded(args, swmi, np, torch, local_rank)
@@ -299,14 +318,15 @@ def main():
         return bench_semiglobal(args, swmi, np, torch, local_rank)
     P = args.pairs
     n_total = P * world
+    collective = world > 1 or args.force_dist   # the score gather (and the barriers) run whenever a process group exists
     lo, hi = sharding.shard_bounds(n_total, rank, world)        # contiguous shard of the global pair index space
     dev = torch.device("cuda", local_rank)
     d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     p1 = p2 = None
     # two score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernel of step k+1
-    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
-    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else scores
+    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2 if collective else 1)]
+    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(2)] if collective else scores
     pending = [None, None]
     stream = torch.cuda.current_stream()
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
@@ -334,7 +354,7 @@ def main():
         launch(scores[buf].data_ptr())
         if ev is not None:
             ev[1].record(stream)
-        if world > 1:
+        if collective:
             pending[buf] = dist.all_gather_into_tensor(gathered[buf], scores[buf], async_op=True)
 
     def drain():
@@ -353,17 +373,17 @@ def main():
         step(k)
     drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, events[k])
     drain()
-    if world > 1:
+    if collective:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -372,7 +392,7 @@ def main():
     # every rank must hold the same, complete score vector after the gather
     last = (args.steps - 1) % len(scores)
     checksum = int(gathered[last].to(torch.int64).sum().item())
-    if world > 1:
+    if collective:
         c = torch.tensor([checksum], dtype=torch.int64, device=dev)
         cmin, cmax = c.clone(), c.clone()
         dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
@@ -426,7 +446,7 @@ def main():
                                        {"pairs": "BASELINE.json configs[1]", "packed": "SURVEY 8f N3 (2-bit packed inputs, source.cpp:1581)",
                                         "one-vs-many": "SURVEY 8f N1 (every seq1 vs ONE seq2, source.cpp:1227)"}[args.mode],
                                        P, args.match, args.mismatch, args.gap,
-                                       ", RCCL all-gather of scores each step (overlapped with the next step's kernel)" if world > 1 else ""),
+                                       ", RCCL all-gather of scores each step (overlapped with the next step's kernel)" if collective else ""),
                        "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
                        "parallelism": "batch-sharded x%d" % world},
             "roofline": roof, "checksum": checksum,
@@ -445,7 +465,7 @@ def main():
                                         "ms": round(dt3 * 1e3, 3), "value": round(P / dt3, 1), "unit": "alignments/s",
                                         "matches_resident_scores": bool((hs == scores[0].cpu().numpy()).all())}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     return 0
