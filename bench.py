@@ -234,6 +234,29 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
                                    "substitutions (SpeedtestSemiGlobal inputs), band 32, X-drop 70, score + full traceback, "
                                    "inputs resident in HBM" % P},
             "mean_score": float(scores.float().mean().item()), "mean_traceback_len": float(lengths.float().mean().item())}
+    # per-kernel durations from HIP events on the launch stream (swmi_semiglobal_time_device), averaged over 3 calls
+    phases = [swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap,
+                                          lengths.data_ptr(), stream.cuda_stream) for _ in range(3)]
+    sweep_ms = sum(p[0] for p in phases) / 3
+    tb_ms = sum(p[1] for p in phases) / 3
+    # algorithmic work of the sweep (source.cpp:1914-1941): per band cell 1 lookup+add, 2 sub, 3 max into the cell, 1 max
+    # into the round maximum, compare+select of the X-drop = 9 int ops; 32 cells per round; these inputs never drop out,
+    # so every alignment runs the full 32768 rounds
+    rounds, ops_cell = 32768, 9
+    sweep_ops = P * rounds * 32 * ops_cell
+    alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
+    line["roofline"] = {
+        "bound": "valu", "kernel": "sg_forward_lane_kernel" if P >= 32768 else "sg_forward_kernel",
+        "kernel_ms": round(sweep_ms, 3), "achieved": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),
+        "peak": round(VALU_PEAK_TOPS, 1), "unit": "TOP/s (int32)",
+        "frac": round(sweep_ops / (sweep_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+        "algorithmic_ops_per_launch": sweep_ops, "gcups_kernel": round(P * rounds * 32 / (sweep_ms * 1e-3) / 1e9, 1),
+        "traffic": None,
+        "traceback_kernel_ms": round(tb_ms, 3),
+        "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / ((sweep_ms + tb_ms) * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / ((sweep_ms + tb_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "sequences in + (i, j) pairs out; the predecessor records between the two kernels (10 B per round, "
+                        "written once and read once) are implementation traffic on top"}}
     if not args.no_cpu_baseline:
         ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
         sample = 64

@@ -148,6 +148,11 @@ SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, s
  * workspace of ~0.33 MB per alignment (2-bit predecessor codes + band rows), grown on demand. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
+/* Measurement helper (no reference counterpart): one swmi_semiglobal_xdrop_device call bracketed by HIP events on
+ * `stream`, synchronous; phase_ms[0] = the sweep kernel (source.cpp:1886-1949), phase_ms[1] = the traceback kernel
+ * (source.cpp:1951-1975). */
+SWMI_API int swmi_semiglobal_time_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
+                                         void *d_tracebacks, size_t cap, void *d_lengths, void *stream, float phase_ms[2]);
 
 /* unpack() itself (source.cpp:1580-1583) for n packed sequences, on the GPU. Host buffers. */
 SWMI_API int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked);

@@ -394,8 +394,12 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
 
 // Traceback, one LANE per alignment (large batches): the wave-per-alignment walker above is bound by the scalar unit
 // (one walk per wavefront, ~40 scalar instructions per step); here 64 walks advance per vector instruction.  Each lane
-// keeps the 64-byte line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS and refills it
-// from global memory when the walk leaves it; two walks (count, then write each position at its final index).
+// keeps the 64-byte line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS.
+// The 64 walks of a wavefront move in LOCKSTEP BY WINDOW of 8 rounds: all lanes consume window w (each at its own pace,
+// 4..8 steps), then the whole wavefront swaps in the line of window w-1, which was requested before window w was
+// walked.  (Refilling per lane, whenever a walk left its line, made almost every step wait for some lane's load: 64
+// walks at random phases, one dependent HBM access per ~5 steps each.)  Two walks: count, then write each position at
+// its final (ascending) index.
 __global__ void __launch_bounds__(64)
 sg_traceback_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
                          const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
@@ -404,51 +408,72 @@ sg_traceback_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const u
     __shared__ uint4 line_codes[64][4 + 1];               // [lane][16-byte quarter of the line], padded
     __shared__ uint4 line_top[64][4 + 1];
     const int lane = threadIdx.x;
-    const uint32_t a = blockIdx.x * 64 + threadIdx.x;
-    if (a >= n) return;                                   // no wave-level synchronisation below: lanes are independent
+    const uint32_t a0 = blockIdx.x * 64 + threadIdx.x;
+    const bool real = a0 < n;
+    const uint32_t a = real ? a0 : n - 1;                 // tail lanes shadow the last alignment and store nothing
     const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
     const uint4 *my_top = reinterpret_cast<const uint4 *>(top_y + (size_t)a * kTopStride);
     const int4 sum = summary[a];
     const int y0 = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
-    const int x0 = sum.y - y0;
+    const int x0 = sum.y - y0;                            // y0 + x0 = the round of the best cell
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
+    // first window of the wavefront = the highest one any of its walks starts in
+    int wmax = sum.y >> 3;
+    wmax = row16_max(wmax);
+    wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
+               max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
 
     uint32_t total = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int y = y0, x = x0;
-        int have_codes = -1, have_top = -1;               // line numbers currently staged
+        bool walking = (y | x) != 0;
         uint32_t count = 1;
         uint32_t idx = total - 1;                         // pass 1: index of the current position in the ascending list
-        if (pass == 1 && idx < cap) out[idx] = make_int2(y, x);
-        while ((y | x) != 0) {
-            const int r = y + x;
-            if ((r >> 3) != have_codes) {
-                have_codes = r >> 3;
+        if (pass == 1 && real && idx < cap) out[idx] = make_int2(y, x);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) line_codes[lane][q] = my_codes[4 * have_codes + q];
+        for (int q = 0; q < 4; ++q) {
+            line_codes[lane][q] = my_codes[4 * wmax + q];
+            line_top[lane][q] = my_top[4 * (wmax >> 2) + q];
+        }
+        for (int w = wmax; w >= 0; --w) {
+            // request the lines of window w - 1 now; they are needed only after window w has been walked
+            // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
+            const int wp = w > 0 ? w - 1 : 0;
+            const bool top_changes = (w & 3) == 0;        // window w - 1 lies in the previous 32-round line of band rows
+            const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
+            uint4 nt0 = make_uint4(0, 0, 0, 0), nt1 = nt0, nt2 = nt0, nt3 = nt0;
+            if (top_changes) {
+                const uint4 *tp = my_top + 4 * (wp >> 2);
+                nt0 = tp[0]; nt1 = tp[1]; nt2 = tp[2]; nt3 = tp[3];
             }
-            if ((r >> 5) != have_top) {
-                have_top = r >> 5;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) line_top[lane][q] = my_top[4 * have_top + q];
+            while (walking && ((y + x) >> 3) == w) {
+                const int r = y + x;
+                const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
+                const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
+                const int bl = 31 - (y - top);
+                const int code = (int)((cw.x >> bl) & 1u) | (int)(((cw.y >> bl) & 1u) << 1);
+                y -= (code == 1 || code == 2) ? 1 : 0;    // 1 diag, 2 up: one row back
+                x -= (code == 1 || code == 3) ? 1 : 0;    // 1 diag, 3 left: one column back
+                walking = code != 0 && (y | x) != 0;      // code 0 cannot happen for a cell on a live path
+                if (code != 0) {
+                    ++count;
+                    if (pass == 1) {
+                        --idx;
+                        if (real && idx < cap) out[idx] = make_int2(y, x);
+                    }
+                }
             }
-            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
-            const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
-            const int bl = 31 - (y - top);
-            const int code = (int)((cw.x >> bl) & 1u) | (int)(((cw.y >> bl) & 1u) << 1);
-            if (code == 0) break;                         // cannot happen for a cell on a live path
-            y -= (code != 3) ? 1 : 0;                     // 1 diag, 2 up: one row back
-            x -= (code != 2) ? 1 : 0;                     // 1 diag, 3 left: one column back
-            ++count;
-            if (pass == 1) {
-                --idx;
-                if (idx < cap) out[idx] = make_int2(y, x);
+            line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
+            if (top_changes) {
+                line_top[lane][0] = nt0; line_top[lane][1] = nt1; line_top[lane][2] = nt2; line_top[lane][3] = nt3;
             }
         }
         total = count;
     }
-    scores[a] = sum.x;
-    lengths[a] = total;
+    if (real) {
+        scores[a] = sum.x;
+        lengths[a] = total;
+    }
 }
 
 }  // namespace
@@ -465,7 +490,8 @@ size_t semiglobal_workspace_bytes(size_t n)
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
-                             int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream)
+                             int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
+                             hipEvent_t between)
 {
     if (n == 0) return hipSuccess;
     char *ws = static_cast<char *>(d_workspace);
@@ -487,6 +513,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
                            top, summary);
     }
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
     const char *force_tb = getenv("SWMI_SG_TRACEBACK");
     const bool lane_tb = force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;

@@ -463,8 +463,8 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
     return SWMI_OK;
 }
 
-int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
-                                 size_t cap, void *d_lengths, void *stream)
+static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
+                             size_t cap, void *d_lengths, void *stream, hipEvent_t between)
 {
     if (n == 0) return SWMI_OK;
     if (!d_seq1s || !d_seq2s || !d_scores || !d_lengths || (!d_tracebacks && cap != 0))
@@ -486,8 +486,37 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
     }
     HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n,
                                     g_ctx.sg_workspace, static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks),
-                                    cap, static_cast<uint32_t *>(d_lengths), static_cast<hipStream_t>(stream)));
+                                    cap, static_cast<uint32_t *>(d_lengths), static_cast<hipStream_t>(stream), between));
     return SWMI_OK;
+}
+
+int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
+                                 size_t cap, void *d_lengths, void *stream)
+{
+    return semiglobal_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, nullptr);
+}
+
+int swmi_semiglobal_time_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
+                                size_t cap, void *d_lengths, void *stream, float phase_ms[2])
+{
+    if (!phase_ms) return fail(SWMI_ERR_INVALID_ARGUMENT, "phase_ms is NULL");
+    if (n == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "n is 0");
+    int rc = check_ready();
+    if (rc != SWMI_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < 3 && he == hipSuccess; ++k) he = hipEventCreate(&ev[k]);
+    if (he == hipSuccess) he = hipEventRecord(ev[0], st);
+    if (he == hipSuccess) rc = semiglobal_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, ev[1]);
+    if (he == hipSuccess && rc == SWMI_OK) he = hipEventRecord(ev[2], st);
+    if (he == hipSuccess && rc == SWMI_OK) he = hipEventSynchronize(ev[2]);
+    if (he == hipSuccess && rc == SWMI_OK) he = hipEventElapsedTime(&phase_ms[0], ev[0], ev[1]);
+    if (he == hipSuccess && rc == SWMI_OK) he = hipEventElapsedTime(&phase_ms[1], ev[1], ev[2]);
+    for (int k = 0; k < 3; ++k)
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+    if (he != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_semiglobal_time_device: %s", hipGetErrorString(he));
+    return rc;
 }
 
 int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, int32_t *tracebacks,

@@ -44,6 +44,7 @@ bool schedule_supported(int lanes_per_alignment);
 // Semi-global adaptive-band X-drop aligner (sg_kernels.hip). Workspace: codes + band rows + summaries for n alignments.
 size_t semiglobal_workspace_bytes(size_t n);
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
-                             int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream);
+                             int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
+                             hipEvent_t between = nullptr);   // recorded between the sweep and the traceback kernel
 
 }  // namespace swmi

@@ -68,6 +68,7 @@ def load():
     lib.swmi_unpack.argtypes = [vp, sz, vp]
     lib.swmi_semiglobal_xdrop.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.swmi_semiglobal_xdrop_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    lib.swmi_semiglobal_time_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
     lib.swmi_score_banded_affine_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.swmi_queue_create.argtypes = [sz, vp, i8, ctypes.POINTER(vp)]
@@ -216,6 +217,13 @@ def semiglobal_xdrop(seq1s, seq2s, cap=SG_MAX_TRACEBACK):
 
 def semiglobal_xdrop_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream=0):
     _check(load().swmi_semiglobal_xdrop_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream))
+
+
+def semiglobal_time_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream=0):
+    """(sweep_ms, traceback_ms) of one device call, from HIP events on `stream`."""
+    ms = (ctypes.c_float * 2)()
+    _check(load().swmi_semiglobal_time_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, ms))
+    return float(ms[0]), float(ms[1])
 
 
 def unpack(packed):

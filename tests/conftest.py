@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libswmi.so: a process that uses both must load torch's HIP runtime first)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "smith-waterman-simd_amd")

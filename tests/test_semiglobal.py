@@ -94,3 +94,26 @@ def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep, trac
     assert np.array_equal(tbs[0], np.stack([np.arange(100), np.arange(100)], axis=1))   # the first 100 steps of the diagonal
     s0, t0, l0 = gpu.semiglobal_xdrop(np.zeros((0, 16384), np.uint8), np.zeros((0, 16384), np.uint8))
     assert s0.shape == (0,) and t0 == []
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_phase_timing_entry(gpu, oracle):
+    """swmi_semiglobal_time_device: same results as the plain device call, two positive kernel durations."""
+    import torch
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 4, (3, 16384), dtype=np.uint8)
+    b = a.copy()
+    b[:, ::37] = rng.integers(0, 4, b[:, ::37].shape, dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    d1, d2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    cap = gpu.SG_MAX_TRACEBACK
+    scores = torch.zeros(3, dtype=torch.int32, device=dev)
+    lengths = torch.zeros(3, dtype=torch.int32, device=dev)
+    tb = torch.zeros((3, cap, 2), dtype=torch.int32, device=dev)
+    sweep_ms, tb_ms = gpu.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), 3, scores.data_ptr(), tb.data_ptr(), cap,
+                                                 lengths.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert sweep_ms > 0 and tb_ms > 0
+    for k in range(3):
+        want_score, want_tb = oracle.semiglobal(a[k], b[k])
+        assert int(scores[k]) == want_score and int(lengths[k]) == len(want_tb)
+        assert np.array_equal(tb[k, : len(want_tb)].cpu().numpy(), want_tb)
