@@ -246,7 +246,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     sweep_ops = P * rounds * 32 * ops_cell
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
     line["roofline"] = {
-        "bound": "valu", "kernel": "sg_forward_lane_kernel" if P >= 32768 else "sg_forward_kernel",
+        "bound": "valu", "kernel": "sg_forward_split_kernel<2>" if P >= 98304 else "sg_forward_split_kernel<4>" if P >= 6144 else "sg_forward_kernel",
         "kernel_ms": round(sweep_ms, 3), "achieved": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),
         "peak": round(VALU_PEAK_TOPS, 1), "unit": "TOP/s (int32)",
         "frac": round(sweep_ops / (sweep_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),

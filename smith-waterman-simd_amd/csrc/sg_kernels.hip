@@ -15,6 +15,7 @@
 #include "swmi_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace swmi {
 namespace {
@@ -25,8 +26,10 @@ constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
 // per-alignment row strides of the sweep's records, padded so that every alignment starts on a 64-byte line
 constexpr int kCodeStride = (kMaxRound + 7) & ~7;        // uint2 entries (8 B): 262208 B per alignment
 constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 65600 B per alignment
-constexpr size_t kLaneSweepMinBatch = 32768;
-constexpr size_t kLaneTracebackMinBatch = 32768; // from here on the lane-per-alignment sweep wins
+// which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
+constexpr size_t kSplit4MinBatch = 6144;         // band over 4 lanes from here on, over 2 lanes from kSplit2MinBatch on
+constexpr size_t kSplit2MinBatch = 98304;
+constexpr size_t kLaneTracebackMinBatch = 6144;  // one lane per walk from here on
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
 __device__ __forceinline__ int row16_max(int v)
@@ -140,47 +143,95 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     if (writer) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
 }
 
-// ---- sweep, one LANE per alignment (large batches) -----------------------------------------------------------
+constexpr int kNeg = -(1 << 24);                       // a dropped cell in the split sweep (the reference stores 0)
+
+// ---- character streams for the split sweep -------------------------------------------------------------------------
 //
-// Same results as sg_forward_kernel, different mapping: every lane sweeps its own alignment with the 32 band cells in
-// registers, so a round needs no cross-lane instruction at all and a wavefront advances 64 alignments per ~16
-// instructions per cell (the band-per-half-wave kernel above spends ~117 instructions per round on two alignments, most
-// of them cross-lane plumbing).  It needs >= 64 alignments per wavefront to pay, i.e. large batches; the launcher picks.
+// The band consumes seq1 top to bottom and seq2 left to right, one character per move, and only ever the next one.  A
+// pre-pass rewrites both sequences of every alignment as streams of 4-bit fields, 16 per 64-bit word: the base (0..3), and
+// past the end of the sequence the pad the reference appends (source.cpp:1861-1873) -- 8 for seq1, 4 for seq2, so that a
+// pad never equals a base or the other pad.  The sweep then needs no index arithmetic, range checks or byte extraction:
+// next character = low field of a 64-bit shift register, refilled every 16 moves with one prefetched load.
+constexpr int kStreamWords = (kLen + 128) / 16;          // 16 fields per word; 128 fields of pad cover every read-ahead
+
+__global__ void __launch_bounds__(256)
+sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
+                       unsigned long long *__restrict__ streams)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;              // one thread per output word
+    const size_t per_alignment = 2 * (size_t)kStreamWords;
+    if (t >= (size_t)n * per_alignment) return;
+    const uint32_t a = (uint32_t)(t / per_alignment);
+    const uint32_t w = (uint32_t)(t % per_alignment);
+    const bool second = w >= (uint32_t)kStreamWords;                      // words [0, kStreamWords) = seq1, then seq2
+    const uint32_t j = second ? w - kStreamWords : w;                     // characters 16 j .. 16 j + 15
+    unsigned long long out;
+    if (j < (uint32_t)(kLen / 16)) {
+        const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * j);
+        auto squeeze = [](unsigned v) -> unsigned long long {             // 4 bytes (0..3 each) -> 4 fields
+            v &= 0x03030303u;
+            v = (v | (v >> 4)) & 0x00FF00FFu;
+            return (unsigned long long)((v | (v >> 8)) & 0xFFFFu);
+        };
+        out = squeeze(b.x) | (squeeze(b.y) << 16) | (squeeze(b.z) << 32) | (squeeze(b.w) << 48);
+    } else {
+        out = second ? 0x4444444444444444ull : 0x8888888888888888ull;
+    }
+    streams[t] = out;
+}
+
+// ---- sweep, G lanes per alignment (C = 32 / G band cells per lane) -------------------------------------------------
+//
+// Same results as sg_forward_kernel, different mapping: each lane keeps C cells of the band in registers, so most of a
+// round is plain per-lane arithmetic (~14 instructions per cell, against ~58 per one-cell lane above, most of those
+// cross-lane plumbing).  What crosses lanes per round is small: the two cells next to the lane's slice, one sequence
+// character in each direction, the band's two end cells (direction) and the band maximum -- all DPP moves inside a row
+// of 16 lanes.  (A whole band per lane, G = 1, was the first version: 64 alignments per wavefront and ~200 VGPRs leave
+// one or two wavefronts per SIMD and nothing to hide latencies behind; it lost to G = 2 and G = 4 at every batch size.)
 //   * dropped cells hold kNeg instead of 0: the != 0 guards of source.cpp:1922-1924 then fall out of max3, and the
 //     X-drop test "v < max(best - 70, 1)" resets every dropped cell to exactly kNeg each round;
-//   * the sequences ride along as two 64-bit windows of 2-bit fields (cell k <-> field k), shifted by one field per
-//     move; one XOR gives the match/mismatch field of all 32 cells;
-//   * the band maximum and the lane that holds it come from one max over keys (value << 5 | lane);
-//   * predecessor codes are collected as three 32-bit words per round (vd == v, vd == v || vu != v, live).
-constexpr int kNeg = -(1 << 24);
-
+//   * one shifted view S[j] = right ? P[j] : P[j-1] of the previous round's cells serves as `left` (S[k]) and `up`
+//     (S[k+1]); last round's view gives the diagonal (right ? S'[k+1] : S'[k]): two selects per cell and C+1 registers;
+//     the -1 of the gap is applied to the view once, not per use;
+//   * sequence characters are 4-bit fields (0..3, pads 8 / 4: a pad never matches) in one window per sequence, cell c <->
+//     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells;
+//   * the band maximum and the cell that holds it come from one max over keys (value << 5 | cell);
+//   * predecessor codes are collected as two C-bit words per round (vd != v, vu != v), shifted in as the sign of the
+//     difference; dropped cells carry no "live" bit: a path never enters a dropped cell (its value cannot equal a live
+//     cell's predecessor value), so the traceback never reads that bit.
+template <int G>
 __global__ void __launch_bounds__(64)
-sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
-                       uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
+sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
+                        uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
 {
-    // Per-lane records are staged in LDS and leave as whole 64-byte lines: every 8 rounds (codes) / 32 rounds (band rows)
-    // the wavefront writes, per instruction, the lines of 16 alignments (4 lanes x 16 B each).  Storing 8 + 2 bytes per
-    // lane per round directly would issue 128 partial-line requests per round and leave the sweep waiting on the TA.
-    __shared__ uint2 stage_codes[64][8];                  // [alignment of the block][round & 7]
-    __shared__ uint16_t stage_top[64][32];                // [alignment of the block][round & 31]
+    constexpr int C = 32 / G;                             // band cells per lane
+    constexpr int A = 64 / G;                             // alignments per wavefront
+    static_assert(G == 2 || G == 4, "the cross-lane moves below are written for quads");
+    using win_t = typename std::conditional<C == 8, uint32_t, unsigned long long>::type;   // C 4-bit fields
+    constexpr win_t kOnes = (win_t)0x1111111111111111ull;
+    __shared__ uint2 stage_codes[A][8];                   // [alignment of the block][round & 7]
+    __shared__ uint16_t stage_top[A][32];                 // [alignment of the block][round & 31]
     const int lane = threadIdx.x;
-    const uint32_t block_first = blockIdx.x * 64;
-    const uint32_t a0 = block_first + threadIdx.x;
+    const int g = lane & (G - 1);                         // slice of the band: cells g*C .. g*C + C-1
+    const int al = lane / G;                              // alignment of the block
+    const bool is_first = g == 0, is_last = g == G - 1;
+    const uint32_t block_first = blockIdx.x * A;
+    const uint32_t a0 = block_first + al;
     const bool real = a0 < n;
     const uint32_t a = real ? a0 : n - 1;
-    const uint8_t *s1 = seq1s + (size_t)a * kLen;
-    const uint8_t *s2 = seq2s + (size_t)a * kLen;
-    // group-of-8-rounds `g8` (rounds 8*g8 .. 8*g8+7) of all 64 alignments -> global, 4 x 16 lines
+    const unsigned long long *stream_a = streams + (size_t)a * (2 * kStreamWords);
+    const unsigned long long *stream_b = stream_a + kStreamWords;
+    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 8);       // this slice's bytes of word 0
     auto flush_codes = [&](int g8) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int al = q * 16 + (lane >> 2), part = lane & 3;
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[al][2 * part]);
-            if (block_first + al < n)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + al) * kCodeStride + 8 * g8 + 2 * part) = v;
+        for (int q = 0; q < A / 16; ++q) {
+            const int fa = q * 16 + (lane >> 2), part = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
+            if (block_first + fa < n)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + fa) * kCodeStride + 8 * g8 + 2 * part) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -189,96 +240,128 @@ sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int al = q * 16 + (lane >> 2), part = lane & 3;
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_top[al][8 * part]);
-            if (block_first + al < n)
-                *reinterpret_cast<uint4 *>(top_y + (size_t)(block_first + al) * kTopStride + 32 * g32 + 8 * part) = v;
+        for (int q = 0; q < A / 16; ++q) {
+            const int fa = q * 16 + (lane >> 2), part = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_top[fa][8 * part]);
+            if (block_first + fa < n)
+                *reinterpret_cast<uint4 *>(top_y + (size_t)(block_first + fa) * kTopStride + 32 * g32 + 8 * part) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
+    // value of lane g-1 / g+1 of the same alignment (garbage at the slice ends: the callers select it away)
+    auto from_prev = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true); };
+    auto from_next = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, true); };
+    auto group_first = [](int v) {                        // lane 0 of the group, in every lane of the group
+        return __builtin_amdgcn_update_dpp(0, v, G == 4 ? 0x00 /* quad_perm:[0,0,0,0] */ : 0xA0 /* [0,0,2,2] */, 0xf, 0xf, true);
+    };
+    auto group_last = [](int v) {
+        return __builtin_amdgcn_update_dpp(0, v, G == 4 ? 0xFF /* quad_perm:[3,3,3,3] */ : 0xF5 /* [1,1,3,3] */, 0xf, 0xf, true);
+    };
+    auto group_max = [](int v) {
+        int o = __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+        v = v > o ? v : o;
+        if (G == 4) {
+            o = __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+            v = v > o ? v : o;
+        }
+        return v;
+    };
 
-    int cur[32], hor[32], ver[32];
+    int cur[C], spm[C + 1];                               // cells of the previous round; its shifted view minus 1
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { cur[k] = kNeg; hor[k] = kNeg; ver[k] = kNeg; }
-    cur[31] = kXDrop;
+    for (int c = 0; c < C; ++c) cur[c] = kNeg;
+#pragma unroll
+    for (int c = 0; c <= C; ++c) spm[c] = kNeg;
+    if (is_last) cur[C - 1] = kXDrop;
     // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
-    unsigned long long aw = 0, av = 0, bw = 0, bv = 0;
+    win_t aw = 0, bw = 0;
+    {
+        const unsigned long long w0 = stream_a[0], w1 = stream_a[1];         // seq1[0..31]
 #pragma unroll
-    for (int k = 0; k <= 30; ++k) {
-        aw |= (unsigned long long)(s1[30 - k] & 3u) << (2 * k);
-        av |= 3ull << (2 * k);
+        for (int c = 0; c < C; ++c) {
+            const int i1 = 30 - (g * C + c);                                  // differs per lane: shifts, not indexing
+            const unsigned ch = (unsigned)(((i1 & 16) ? w1 : w0) >> (4 * (i1 & 15))) & 15u;
+            aw |= (win_t)(i1 >= 0 ? ch : 8u) << (4 * c);
+            bw |= (win_t)4u << (4 * c);
+        }
     }
     int pos_x = 31;
     int best = kXDrop, best_round = 0, best_lane = 31, rounds = 1, last_round = 0;
     bool alive = true;
-    stage_codes[lane][0] = make_uint2(0, 0);
-    stage_top[lane][0] = 0;
-    // sequence characters arrive 16 at a time, one 16-byte load per lane per 16 consumed characters, fetched one
-    // buffer ahead (the load has 16 moves to land)
-    uint4 abuf = *reinterpret_cast<const uint4 *>(s1 + 16);    // seq1[16..31]: the next step down consumes seq1[31]
-    uint4 anext = *reinterpret_cast<const uint4 *>(s1 + 32);
-    uint4 bbuf = *reinterpret_cast<const uint4 *>(s2);         // seq2[0..15]:  the next step right consumes seq2[0]
-    uint4 bnext = *reinterpret_cast<const uint4 *>(s2 + 16);
-    auto pick = [](const uint4 &buf, int idx) -> unsigned {    // character idx & 15 of the buffered 16
-        const unsigned w = (idx & 8) ? ((idx & 4) ? buf.w : buf.z) : ((idx & 4) ? buf.y : buf.x);
-        return (w >> (8 * (idx & 3))) & 3u;
-    };
+    if (is_first) { stage_codes[al][0] = make_uint2(0, 0); stage_top[al][0] = 0; }
+    // This lane's character stream: the first slice feeds on seq1 (consumed when the band steps down), the last slice on
+    // seq2 (consumed when it steps right); slices in between run the seq1 stream along without using it.
+    const unsigned long long *my_stream = is_last ? stream_b : stream_a;
+    int s_idx = is_last ? 0 : 31;                         // next character: seq2[0] / seq1[31]
+    unsigned s_lo, s_hi, n_lo, n_hi;                      // shift register (next character in the low field), prefetched word
+    {
+        const unsigned long long w = my_stream[s_idx >> 4] >> (4 * (s_idx & 15)), nw = my_stream[(s_idx >> 4) + 1];
+        s_lo = (unsigned)w; s_hi = (unsigned)(w >> 32);
+        n_lo = (unsigned)nw; n_hi = (unsigned)(nw >> 32);
+    }
 
     for (int round = 1; round < kMaxRound; ++round) {
         if (!__any(alive)) break;
-        const bool right = cur[0] < cur[31];              // source.cpp:1895
+        const bool right = group_first(cur[0]) < group_last(cur[C - 1]);      // source.cpp:1895
         pos_x += right ? 1 : 0;
         const int pos_y = round - (pos_x - 31);
         alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
+        // neighbours of the slice in the previous round's band
+        const int p_lo = from_prev(cur[C - 1]), p_hi = from_next(cur[0]);
+        const int lo_in = is_first ? kNeg : p_lo, hi_in = is_last ? kNeg : p_hi;
         // sequence windows follow the band
         {
-            const int ia = pos_y + 30, ib = pos_x - 32;   // 0-based index of the character that has just entered
-            const bool va = (unsigned)ia < (unsigned)kLen, vb = (unsigned)ib < (unsigned)kLen;
-            const unsigned cand_a = pick(abuf, ia), cand_b = pick(bbuf, ib);
-            const unsigned long long aw_d = (aw << 2) | cand_a, av_d = (av << 2) | (va ? 3ull : 0ull);
-            const unsigned long long bw_r = (bw >> 2) | ((unsigned long long)cand_b << 62), bv_r = (bv >> 2) | (vb ? 3ull << 62 : 0ull);
-            aw = right ? aw : aw_d;  av = right ? av : av_d;
-            bw = right ? bw_r : bw;  bv = right ? bv_r : bv;
-            // a buffer whose last character (index 15 mod 16) has just been consumed is replaced by the prefetched one
-            if (!right && (ia & 15) == 15) {
-                abuf = anext;
-                if (ia + 17 < kLen) anext = *reinterpret_cast<const uint4 *>(s1 + ia + 17);
-            }
-            if (right && (ib & 15) == 15) {
-                bbuf = bnext;
-                if (ib + 17 < kLen) bnext = *reinterpret_cast<const uint4 *>(s2 + ib + 17);
+            const unsigned cand = s_lo & 15u;             // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
+            const unsigned a_top = (unsigned)(aw >> (4 * C - 4)), b_low = (unsigned)bw & 15u;
+            // (the DPP moves are evaluated by ALL lanes before the select: inside one arm of `?:` they would run with the
+            // source lanes masked off)
+            const unsigned a_nb = (unsigned)from_prev((int)a_top), b_nb = (unsigned)from_next((int)b_low);
+            const unsigned a_in = is_first ? cand : a_nb;
+            const unsigned b_in = is_last ? cand : b_nb;
+            const win_t aw_d = (aw << 4) | a_in;
+            const win_t bw_r = (bw >> 4) | ((win_t)b_in << (4 * C - 4));
+            aw = right ? aw : aw_d;
+            bw = right ? bw_r : bw;
+            const bool consume = is_last ? right : !right;
+            const unsigned sh_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, 4), sh_hi = s_hi >> 4;
+            s_lo = consume ? sh_lo : s_lo;
+            s_hi = consume ? sh_hi : s_hi;
+            s_idx += consume ? 1 : 0;
+            if (consume && (s_idx & 15) == 0) {           // sixteen consumed: take the prefetched word, request the one after
+                s_lo = n_lo; s_hi = n_hi;
+                const int next_word = (s_idx >> 4) + 1;   // a band that has left the matrix keeps stepping: stay inside the stream
+                const unsigned long long nw = my_stream[next_word < kStreamWords ? next_word : kStreamWords - 1];
+                n_lo = (unsigned)nw; n_hi = (unsigned)(nw >> 32);
             }
         }
-        const unsigned long long x = aw ^ bw;
-        const unsigned long long same = ~(x | (x >> 1)) & 0x5555555555555555ull & av & bv;   // bit 2k: cell k is a match
-        const unsigned long long m2 = same << 1;                                            // field k = 2 (match) or 0
-        const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32);
+        win_t z = aw ^ bw;
+        z |= z >> 1;
+        z |= z >> 2;
+        const win_t m2 = (~z & kOnes) << 1;               // field c = 2 (match) or 0
+        const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)((unsigned long long)m2 >> 32);
 
         int kmax = kNeg;
-        unsigned w_nd = 0, w_nu = 0;                      // bit k: vd != v0 / vu != v0, shifted in as the sign of the difference
-        int pending = 0;                                  // new value of cell k+1, written once cell k no longer needs the old one
+        unsigned w_nd = 0, w_nu = 0;                      // bit c: vd != v0 / vu != v0, shifted in as the sign of the difference
+        int sm_hi = (right ? hi_in : cur[C - 1]) - 1;     // S[C] - 1
 #pragma unroll
-        for (int k = 31; k >= 0; --k) {
-            const int c_lo = k > 0 ? cur[k - 1] : kNeg, c_mid = cur[k], c_hi = k < 31 ? cur[k + 1] : kNeg;
-            const int dia = right ? ver[k] : hor[k];      // :1897 / :1908
-            const int nh = right ? c_mid : c_lo;          // :1898 / :1910-1911
-            const int nv = right ? c_hi : c_mid;          // :1899-1900 / :1909
-            hor[k] = nh;
-            ver[k] = nv;
-            const int f = (int)(((k < 16 ? m2lo : m2hi) >> (2 * (k & 15))) & 3u);
-            const int vd = dia + f - 1;                   // +1 / -1, :1918-1922
-            const int vu = nv - 1, vl = nh - 1;           // :1923-1924
-            const int m1 = vd > vu ? vd : vu;
-            const int v0 = m1 > vl ? m1 : vl;
-            const int key = (int)(((unsigned)v0 << 5) | (unsigned)k);
+        for (int c = C - 1; c >= 0; --c) {
+            const int below = c > 0 ? cur[c - 1] : lo_in;
+            const int sm_lo = (right ? cur[c] : below) - 1;                   // S[c] - 1 = left - 1 (:1923); sm_hi = up - 1 (:1924)
+            const int dm1 = right ? spm[c + 1] : spm[c];                      // diagonal - 1 (:1897 / :1908)
+            const int f = (int)__builtin_amdgcn_ubfe(c < 8 ? m2lo : m2hi, 4 * (c & 7), 2);
+            const int vd = dm1 + f;                       // +1 / -1, :1918-1922
+            const int m1 = vd > sm_hi ? vd : sm_hi;
+            const int v0 = m1 > sm_lo ? m1 : sm_lo;
+            const int key = (int)(((unsigned)v0 << 5) | (unsigned)(g * C + c));
             kmax = kmax > key ? kmax : key;
-            w_nd = __builtin_amdgcn_alignbit(w_nd, (unsigned)(vd - v0), 31);   // (w << 1) | sign(vd - v0); v0 >= vd always
-            w_nu = __builtin_amdgcn_alignbit(w_nu, (unsigned)(vu - v0), 31);
-            if (k < 31) cur[k + 1] = pending;
-            pending = v0;
+            w_nd = __builtin_amdgcn_alignbit(w_nd, (unsigned)(vd - v0), 31);  // (w << 1) | sign(vd - v0); v0 >= vd always
+            w_nu = __builtin_amdgcn_alignbit(w_nu, (unsigned)(sm_hi - v0), 31);
+            spm[c + 1] = sm_hi;
+            cur[c] = v0;
+            sm_hi = sm_lo;
         }
-        cur[0] = pending;
+        spm[0] = sm_hi;
+        kmax = group_max(kmax);
         const int band_best = kmax >> 5;                  // arithmetic shift: the value part of the winning key
         const int round_best = band_best > 0 ? band_best : 0;
         const bool improved = alive && round_best > best; // :1933-1936
@@ -286,28 +369,27 @@ sg_forward_lane_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         best_round = improved ? round : best_round;
         best_lane = improved ? (kmax & 31) : best_lane;   // highest lane among equals: where the search of :1957 stops
         const int thr = best - kXDrop > 1 ? best - kXDrop : 1;                // :1938-1941, and "0 means dropped"
-        unsigned w_drop = 0;
 #pragma unroll
-        for (int k = 31; k >= 0; --k) {
-            const int d = cur[k] - thr;
-            w_drop = __builtin_amdgcn_alignbit(w_drop, (unsigned)d, 31);
-            cur[k] = d < 0 ? kNeg : cur[k];
+        for (int c = 0; c < C; ++c) cur[c] = cur[c] < thr ? kNeg : cur[c];
+        // codes 1 / 2 / 3 = diag / up / left (:1962-1971): low bit = diagonal or not up, high bit = not diagonal
+        const unsigned word0 = ~w_nd | w_nu, word1 = w_nd;
+        if (C == 8) {
+            my_stage0[8 * (round & 7)] = (uint8_t)word0;
+            my_stage0[8 * (round & 7) + 4] = (uint8_t)word1;
+        } else {
+            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7)) = (uint16_t)word0;
+            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7) + 4) = (uint16_t)word1;
         }
-        const unsigned nz = ~w_drop, wd = ~w_nd, wx = ~w_nd | w_nu;   // live; came by the diagonal; diagonal or not up
-        // codes 1 / 2 / 3 = diag / up / left (:1962-1971).  Rounds past a lane's end are staged and flushed too: they
-        // land beyond `rounds` of that alignment, which the traceback never reads.
-        stage_codes[lane][round & 7] = make_uint2(nz & wx, nz & ~wd);
-        stage_top[lane][round & 31] = (uint16_t)pos_y;
+        if (is_first) stage_top[al][round & 31] = (uint16_t)pos_y;
         if ((round & 7) == 7) flush_codes(round >> 3);
         if ((round & 31) == 31) flush_top(round >> 5);
         rounds = alive ? round + 1 : rounds;
         alive = alive && round_best != 0;                 // :1943-1946
         last_round = round;
     }
-    // the partial groups of the last executed round (uniform across the wavefront)
     if ((last_round & 7) != 7) flush_codes(last_round >> 3);
     if ((last_round & 31) != 31) flush_top(last_round >> 5);
-    if (real) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
+    if (real && is_first) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
 }
 
 // Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
@@ -484,9 +566,11 @@ inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeStride * s
 inline size_t top_bytes(size_t n) { return round16(n * (size_t)kTopStride * sizeof(uint16_t)); }
 }  // namespace
 
+inline size_t streams_bytes(size_t n) { return round16(n * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }
+
 size_t semiglobal_workspace_bytes(size_t n)
 {
-    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4));
+    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n);
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
@@ -498,15 +582,24 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     uint32_t *codes = reinterpret_cast<uint32_t *>(ws);
     uint16_t *top = reinterpret_cast<uint16_t *>(ws + codes_bytes(n));
     int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + top_bytes(n));
+    unsigned long long *streams = reinterpret_cast<unsigned long long *>(ws + codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
-    // two mappings of the sweep, same results: a band per half-wavefront (low latency, fills the chip from a few
-    // thousand alignments) or an alignment per lane (far fewer instructions per alignment, needs a large batch)
+    // three mappings of the sweep, same results: a band per half-wavefront (one cell per lane: low latency, fills the
+    // chip from a few thousand alignments), or the band split over 4 / 2 lanes (8 / 16 cells per lane: far fewer
+    // instructions per alignment, need 16 / 32 alignments per wavefront)
     const char *force = getenv("SWMI_SG_SWEEP");
-    const bool lane_sweep = force ? atoi(force) == 1 : n >= kLaneSweepMinBatch;
-    if (lane_sweep) {
-        hipLaunchKernelGGL(sg_forward_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_seq1s, d_seq2s,
-                           (uint32_t)n, codes, top, summary);
+    const int sweep = force ? atoi(force) : (n >= kSplit2MinBatch ? 2 : n >= kSplit4MinBatch ? 4 : 0);
+    if (sweep == 4 || sweep == 2) {
+        const size_t words = n * 2 * (size_t)kStreamWords;
+        hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
+                           (uint32_t)n, streams);
+        if (sweep == 4)
+            hipLaunchKernelGGL(sg_forward_split_kernel<4>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, streams,
+                               (uint32_t)n, codes, top, summary);
+        else
+            hipLaunchKernelGGL(sg_forward_split_kernel<2>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, stream, streams,
+                               (uint32_t)n, codes, top, summary);
     } else {
         const unsigned waves = (unsigned)((n + 1) / 2);
         hipLaunchKernelGGL(sg_forward_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes,

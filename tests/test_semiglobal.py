@@ -30,8 +30,8 @@ def test_oracle_reproduces_the_reference_results(oracle, golden):
 
 @pytest.fixture
 def sg_kernels(monkeypatch):
-    """Select the sweep / traceback mapping (0 = band per half-wavefront + wave-per-alignment walker, the small-batch
-    pair; 1 = lane per alignment, the large-batch pair).  The library reads the variables at every launch."""
+    """Select the sweep mapping (0 = band per half-wavefront, 4 / 2 = band split over 4 / 2 lanes) and the traceback
+    mapping (0 = wavefront per walk, 1 = lane per walk); by default the batch size decides.  The library reads the variables at every launch."""
     def choose(sweep, traceback):
         monkeypatch.setenv("SWMI_SG_SWEEP", str(sweep))
         monkeypatch.setenv("SWMI_SG_TRACEBACK", str(traceback))
@@ -39,7 +39,7 @@ def sg_kernels(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1), (0, 1), (4, 0), (2, 0)])
 def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep, traceback):
     sg_kernels(sweep, traceback)
     f = golden("f6_semiglobal")
@@ -52,7 +52,7 @@ def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, swee
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1)])
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1)])
 def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, sweep, traceback):
     sg_kernels(sweep, traceback)
     rng = np.random.default_rng(77)
@@ -83,7 +83,7 @@ def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(0, 0), (1, 1)])
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1)])
 def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep, traceback):
     sg_kernels(sweep, traceback)
     rng = np.random.default_rng(4)
