@@ -474,18 +474,26 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     if (lane == 0) { scores[a] = sum.x; lengths[a] = total; }
 }
 
-// Traceback, one LANE per alignment (large batches): the wave-per-alignment walker above is bound by the scalar unit
-// (one walk per wavefront, ~40 scalar instructions per step); here 64 walks advance per vector instruction.  Each lane
-// keeps the 64-byte line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS.
-// The 64 walks of a wavefront move in LOCKSTEP BY WINDOW of 8 rounds: all lanes consume window w (each at its own pace,
-// 4..8 steps), then the whole wavefront swaps in the line of window w-1, which was requested before window w was
-// walked.  (Refilling per lane, whenever a walk left its line, made almost every step wait for some lane's load: 64
-// walks at random phases, one dependent HBM access per ~5 steps each.)  Two walks: count, then write each position at
-// its final (ascending) index.
+// Traceback for large batches, two kernels.
+//
+// sg_walk_lane_kernel: one LANE per walk (the wave-per-alignment walker above is bound by the scalar unit: one walk per
+// wavefront, ~40 scalar instructions per step; here 64 walks advance per vector instruction).  Each lane keeps the 64-byte
+// line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS.  The 64 walks of a wavefront move in
+// LOCKSTEP BY WINDOW of 8 rounds: all lanes consume window w (each at its own pace, 4..8 steps), then the whole wavefront
+// swaps in the line of window w-1, which was requested before window w was walked.  (Refilling per lane, whenever a walk
+// left its line, made almost every step wait for some lane's load: 64 walks at random phases, one dependent HBM access
+// per ~5 steps each.)  The walk does not write positions -- their index in the ascending list is unknown until (0,0) is
+// reached -- but its moves, 2 bits per step (1 diag, 2 up, 3 left), 8 KB per alignment at most.
+//
+// sg_expand_kernel: one wavefront per alignment turns the moves into the (i, j) list of source.cpp:1951-1975, in
+// ascending order from (0,0): position i is the sum of the last i moves of the walk, a prefix sum over the reversed move
+// list -- 64 positions per step, one coalesced 512-byte store each.
+constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
+
 __global__ void __launch_bounds__(64)
-sg_traceback_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
-                         const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
-                         uint32_t cap, uint32_t *__restrict__ lengths)
+sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
+                    const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
+                    int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
 {
     __shared__ uint4 line_codes[64][4 + 1];               // [lane][16-byte quarter of the line], padded
     __shared__ uint4 line_top[64][4 + 1];
@@ -495,66 +503,97 @@ sg_traceback_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const u
     const uint32_t a = real ? a0 : n - 1;                 // tail lanes shadow the last alignment and store nothing
     const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
     const uint4 *my_top = reinterpret_cast<const uint4 *>(top_y + (size_t)a * kTopStride);
+    unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     const int4 sum = summary[a];
-    const int y0 = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
-    const int x0 = sum.y - y0;                            // y0 + x0 = the round of the best cell
-    int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
+    int y = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
+    int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
     int wmax = sum.y >> 3;
     wmax = row16_max(wmax);
     wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
                max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
 
-    uint32_t total = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        int y = y0, x = x0;
-        bool walking = (y | x) != 0;
-        uint32_t count = 1;
-        uint32_t idx = total - 1;                         // pass 1: index of the current position in the ascending list
-        if (pass == 1 && real && idx < cap) out[idx] = make_int2(y, x);
+    bool walking = (y | x) != 0;
+    uint32_t steps = 0;
+    unsigned acc_lo = 0, acc_hi = 0;                      // the last (steps & 31) moves, 2 bits each
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            line_codes[lane][q] = my_codes[4 * wmax + q];
-            line_top[lane][q] = my_top[4 * (wmax >> 2) + q];
+    for (int q = 0; q < 4; ++q) {
+        line_codes[lane][q] = my_codes[4 * wmax + q];
+        line_top[lane][q] = my_top[4 * (wmax >> 2) + q];
+    }
+    for (int w = wmax; w >= 0; --w) {
+        // request the lines of window w - 1 now; they are needed only after window w has been walked
+        // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
+        const int wp = w > 0 ? w - 1 : 0;
+        const bool top_changes = (w & 3) == 0;            // window w - 1 lies in the previous 32-round line of band rows
+        const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
+        uint4 nt0 = make_uint4(0, 0, 0, 0), nt1 = nt0, nt2 = nt0, nt3 = nt0;
+        if (top_changes) {
+            const uint4 *tp = my_top + 4 * (wp >> 2);
+            nt0 = tp[0]; nt1 = tp[1]; nt2 = tp[2]; nt3 = tp[3];
         }
-        for (int w = wmax; w >= 0; --w) {
-            // request the lines of window w - 1 now; they are needed only after window w has been walked
-            // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
-            const int wp = w > 0 ? w - 1 : 0;
-            const bool top_changes = (w & 3) == 0;        // window w - 1 lies in the previous 32-round line of band rows
-            const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
-            uint4 nt0 = make_uint4(0, 0, 0, 0), nt1 = nt0, nt2 = nt0, nt3 = nt0;
-            if (top_changes) {
-                const uint4 *tp = my_top + 4 * (wp >> 2);
-                nt0 = tp[0]; nt1 = tp[1]; nt2 = tp[2]; nt3 = tp[3];
+        while (walking && ((y + x) >> 3) == w) {
+            const int r = y + x;
+            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
+            const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
+            const int bl = 31 - (y - top);
+            const unsigned code = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);   // never 0 on a live path
+            y -= (code == 1 || code == 2) ? 1 : 0;        // 1 diag, 2 up: one row back
+            x -= (code == 1 || code == 3) ? 1 : 0;        // 1 diag, 3 left: one column back
+            const unsigned sh = 2 * (steps & 15u);
+            if (steps & 16u) acc_hi |= code << sh; else acc_lo |= code << sh;
+            ++steps;
+            if ((steps & 31u) == 0) {
+                if (real) my_moves[(steps >> 5) - 1] = ((unsigned long long)acc_hi << 32) | acc_lo;
+                acc_lo = acc_hi = 0;
             }
-            while (walking && ((y + x) >> 3) == w) {
-                const int r = y + x;
-                const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
-                const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
-                const int bl = 31 - (y - top);
-                const int code = (int)((cw.x >> bl) & 1u) | (int)(((cw.y >> bl) & 1u) << 1);
-                y -= (code == 1 || code == 2) ? 1 : 0;    // 1 diag, 2 up: one row back
-                x -= (code == 1 || code == 3) ? 1 : 0;    // 1 diag, 3 left: one column back
-                walking = code != 0 && (y | x) != 0;      // code 0 cannot happen for a cell on a live path
-                if (code != 0) {
-                    ++count;
-                    if (pass == 1) {
-                        --idx;
-                        if (real && idx < cap) out[idx] = make_int2(y, x);
-                    }
-                }
-            }
-            line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
-            if (top_changes) {
-                line_top[lane][0] = nt0; line_top[lane][1] = nt1; line_top[lane][2] = nt2; line_top[lane][3] = nt3;
-            }
+            walking = code != 0 && (y | x) != 0;
         }
-        total = count;
+        line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
+        if (top_changes) {
+            line_top[lane][0] = nt0; line_top[lane][1] = nt1; line_top[lane][2] = nt2; line_top[lane][3] = nt3;
+        }
     }
     if (real) {
+        if (steps & 31u) my_moves[steps >> 5] = ((unsigned long long)acc_hi << 32) | acc_lo;
         scores[a] = sum.x;
-        lengths[a] = total;
+        lengths[a] = steps + 1;                           // positions = moves + 1
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const uint32_t *__restrict__ lengths,
+                 int32_t *__restrict__ tracebacks, uint32_t cap)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wavefront per alignment
+    if (a >= n) return;
+    const unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
+    int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
+    const uint32_t total = lengths[a];                    // positions; moves 0 .. total-2 in walking order
+    const uint32_t limit = total < cap ? total : cap;     // positions to write
+    if (lane == 0 && limit > 0) out[0] = make_int2(0, 0);
+    unsigned carry = 0;                                   // y | x << 16 of position `base`
+    for (uint32_t base = 0; base + 1 < limit; base += 64) {
+        const uint32_t i = base + 1 + (uint32_t)lane;     // this lane's position, reached by move total - 1 - i
+        unsigned d = 0;
+        if (i < total) {
+            const uint32_t t = total - 1 - i;
+            const unsigned code = (unsigned)(my_moves[t >> 5] >> (2 * (t & 31u))) & 3u;
+            d = ((code == 1 || code == 2) ? 1u : 0u) | ((code == 1 || code == 3) ? 0x10000u : 0u);
+        }
+        // inclusive prefix sum over the wavefront (y in the low half, x in the high half: both stay below 2^15)
+        unsigned v = d;
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
+                       r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+        const int row = lane >> 4;
+        v += carry + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+        if (i < limit) out[i] = make_int2((int)(v & 0xFFFFu), (int)(v >> 16));
+        carry += r0 + r1 + r2 + r3;
     }
 }
 
@@ -567,10 +606,11 @@ inline size_t top_bytes(size_t n) { return round16(n * (size_t)kTopStride * size
 }  // namespace
 
 inline size_t streams_bytes(size_t n) { return round16(n * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }
+inline size_t moves_bytes(size_t n) { return round16(n * (size_t)kMoveWords * sizeof(unsigned long long)); }
 
 size_t semiglobal_workspace_bytes(size_t n)
 {
-    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n);
+    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
@@ -583,6 +623,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     uint16_t *top = reinterpret_cast<uint16_t *>(ws + codes_bytes(n));
     int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + top_bytes(n));
     unsigned long long *streams = reinterpret_cast<unsigned long long *>(ws + codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)));
+    unsigned long long *moves = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     // three mappings of the sweep, same results: a band per half-wavefront (one cell per lane: low latency, fills the
@@ -610,9 +651,12 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     if (e != hipSuccess) return e;
     const char *force_tb = getenv("SWMI_SG_TRACEBACK");
     const bool lane_tb = force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;
-    if (lane_tb)
-        hipLaunchKernelGGL(sg_traceback_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
-                           summary, d_scores, d_tracebacks, (uint32_t)cap, d_lengths);
+    if (lane_tb) {
+        hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
+                           summary, moves, d_scores, d_lengths);
+        hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
+                           d_tracebacks, (uint32_t)cap);
+    }
     else
         hipLaunchKernelGGL(sg_traceback_kernel, dim3((unsigned)n), dim3(64), 0, stream, (uint32_t)n, codes, top, summary, d_scores,
                            d_tracebacks, (uint32_t)cap, d_lengths);
