@@ -145,7 +145,8 @@ SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_
 SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
                                    int32_t *tracebacks, size_t cap, uint32_t *lengths);
 /* Same with every buffer resident in device memory; asynchronous on `stream`.  The library keeps a per-process
- * workspace of ~0.33 MB per alignment (2-bit predecessor codes + band rows), grown on demand. */
+ * workspace of ~0.35 MB per alignment (2-bit predecessor codes, band rows, packed character streams, traceback
+ * moves), grown on demand. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
 /* Measurement helper (no reference counterpart): one swmi_semiglobal_xdrop_device call bracketed by HIP events on

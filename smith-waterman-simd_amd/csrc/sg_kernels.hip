@@ -29,7 +29,7 @@ constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 6560
 // which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
 constexpr size_t kSplit4MinBatch = 6144;         // band over 4 lanes from here on, over 2 lanes from kSplit2MinBatch on
 constexpr size_t kSplit2MinBatch = 98304;
-constexpr size_t kLaneTracebackMinBatch = 6144;  // one lane per walk from here on
+constexpr size_t kLaneTracebackMinBatch = 3072;  // one lane per walk (+ expand kernel) from here on
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
 __device__ __forceinline__ int row16_max(int v)
