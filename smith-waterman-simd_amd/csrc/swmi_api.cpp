@@ -530,30 +530,65 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     std::lock_guard<std::mutex> lock(g_ctx.mu);
     HIP_TRY(hipSetDevice(g_ctx.device));
     constexpr size_t kLen = SWMI_SG_LEN;
-    const size_t chunk = n < 2048 ? n : 2048;           // ~0.33 MB of workspace + cap*8 B of output per alignment
-    uint8_t *d1 = nullptr, *d2 = nullptr;
-    void *ws = nullptr;
-    int32_t *d_scores = nullptr, *d_tb = nullptr;
-    uint32_t *d_len = nullptr;
-    hipStream_t st = g_ctx.slots[0].stream;
-    hipError_t e = hipMalloc(&d1, chunk * kLen);
-    if (e == hipSuccess) e = hipMalloc(&d2, chunk * kLen);
-    if (e == hipSuccess) e = hipMalloc(&ws, swmi::semiglobal_workspace_bytes(chunk));
-    if (e == hipSuccess) e = hipMalloc(&d_scores, chunk * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_len, chunk * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_tb, (chunk * (cap ? cap : 1)) * 2 * sizeof(int32_t));
-    for (size_t off = 0; e == hipSuccess && off < n; off += chunk) {
-        const size_t m = n - off < chunk ? n - off : chunk;
-        e = hipMemcpyAsync(d1, seq1s + off * kLen, m * kLen, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(d2, seq2s + off * kLen, m * kLen, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = swmi::launch_semiglobal(d1, d2, m, ws, d_scores, d_tb, cap, d_len, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(scores + off, d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(lengths + off, d_len, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && cap)
-            e = hipMemcpyAsync(tracebacks + off * cap * 2, d_tb, m * cap * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    // Chunks of up to 8192 alignments (~0.35 MB of workspace + cap*8 B of output each), two sets of device buffers: while
+    // the host is busy receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k+1.
+    const size_t chunk = n < 8192 ? n : 8192;
+    struct Set {
+        uint8_t *d1 = nullptr, *d2 = nullptr;
+        void *ws = nullptr;
+        int32_t *d_scores = nullptr, *d_tb = nullptr;
+        uint32_t *d_len = nullptr;
+        hipStream_t st = nullptr;
+        size_t off = 0, m = 0;
+    } sets[2];
+    const int n_sets = n > chunk ? 2 : 1;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_sets && e == hipSuccess; ++k) {
+        Set &s = sets[k];
+        s.st = g_ctx.slots[k].stream;
+        e = hipMalloc(&s.d1, chunk * kLen);
+        if (e == hipSuccess) e = hipMalloc(&s.d2, chunk * kLen);
+        if (e == hipSuccess) e = hipMalloc(&s.ws, swmi::semiglobal_workspace_bytes(chunk));
+        if (e == hipSuccess) e = hipMalloc(&s.d_scores, chunk * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&s.d_len, chunk * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&s.d_tb, (chunk * (cap ? cap : 1)) * 2 * sizeof(int32_t));
     }
-    (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(ws); (void)hipFree(d_scores); (void)hipFree(d_len); (void)hipFree(d_tb);
+    // results of the chunk a set holds -> host; only as many positions per alignment as the longest path of the chunk has
+    auto drain = [&](Set &s) -> hipError_t {
+        if (s.m == 0) return hipSuccess;
+        hipError_t r = hipMemcpyAsync(scores + s.off, s.d_scores, s.m * sizeof(int32_t), hipMemcpyDeviceToHost, s.st);
+        if (r == hipSuccess) r = hipMemcpyAsync(lengths + s.off, s.d_len, s.m * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st);
+        if (r == hipSuccess) r = hipStreamSynchronize(s.st);
+        if (r == hipSuccess && cap) {
+            size_t longest = 0;
+            for (size_t k = 0; k < s.m; ++k) longest = lengths[s.off + k] > longest ? lengths[s.off + k] : longest;
+            if (longest > cap) longest = cap;
+            const size_t pitch = cap * 2 * sizeof(int32_t);
+            r = hipMemcpy2DAsync(tracebacks + s.off * cap * 2, pitch, s.d_tb, pitch, longest * 2 * sizeof(int32_t), s.m,
+                                 hipMemcpyDeviceToHost, s.st);
+            if (r == hipSuccess) r = hipStreamSynchronize(s.st);
+        }
+        s.m = 0;
+        return r;
+    };
+    int turn = 0;
+    for (size_t off = 0; e == hipSuccess && off < n; off += chunk, turn ^= 1) {
+        Set &s = sets[n_sets == 2 ? turn : 0];
+        e = drain(s);                                       // (two chunks ago; normally already empty)
+        if (e != hipSuccess) break;
+        s.off = off;
+        s.m = n - off < chunk ? n - off : chunk;
+        e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, s.st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, s.st);
+        if (e == hipSuccess) e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, s.st);
+        if (e == hipSuccess && n_sets == 2) e = drain(sets[turn ^ 1]);   // the previous chunk, while this one computes
+    }
+    for (int k = 0; k < n_sets; ++k) {
+        if (e == hipSuccess) e = drain(sets[k]);
+        Set &s = sets[k];
+        if (e != hipSuccess && s.st) (void)hipStreamSynchronize(s.st);
+        (void)hipFree(s.d1); (void)hipFree(s.d2); (void)hipFree(s.ws); (void)hipFree(s.d_scores); (void)hipFree(s.d_len); (void)hipFree(s.d_tb);
+    }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_semiglobal_xdrop: %s", hipGetErrorString(e));
     return SWMI_OK;
 }

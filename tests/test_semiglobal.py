@@ -117,3 +117,25 @@ def test_gpu_semiglobal_phase_timing_entry(gpu, oracle):
         want_score, want_tb = oracle.semiglobal(a[k], b[k])
         assert int(scores[k]) == want_score and int(lengths[k]) == len(want_tb)
         assert np.array_equal(tb[k, : len(want_tb)].cpu().numpy(), want_tb)
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_host_entry_pipelines_chunks(gpu, oracle):
+    """swmi_semiglobal_xdrop with more alignments than one chunk (8192): two buffer sets in flight, trimmed 2-D copies."""
+    rng = np.random.default_rng(6)
+    base_a = rng.integers(0, 4, (6, 16384), dtype=np.uint8)
+    base_b = base_a.copy()
+    for k in range(6):
+        idx = rng.integers(0, 16384, 200 * (k + 1))
+        base_b[k, idx] = rng.integers(0, 4, idx.shape, dtype=np.uint8)
+    base_b[5, 9000:] = np.roll(base_b[5], 25)[9000:]                 # one with an indel
+    want = [oracle.semiglobal(base_a[k], base_b[k]) for k in range(6)]
+    n = 8192 + 301
+    pick = rng.integers(0, 6, n)
+    a, b = base_a[pick], base_b[pick]
+    cap = 2048
+    scores, tbs, lengths = gpu.semiglobal_xdrop(a, b, cap=cap)
+    assert np.array_equal(scores, np.array([want[k][0] for k in pick], np.int32))
+    assert np.array_equal(lengths, np.array([len(want[k][1]) for k in pick], np.uint32))
+    for j in range(0, n, 97):
+        assert np.array_equal(tbs[j], want[pick[j]][1][:cap]), j
