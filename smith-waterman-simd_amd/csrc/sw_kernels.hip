@@ -492,8 +492,8 @@ sw128_lut_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ 
 // diagonal 2m+1, with i = 33 - m + u, j = u + m - 31 (1-based).  Neighbours:
 //   even step: left = lane m-1's odd diagonal (DPP wave_shr:1), up = the lane's own odd diagonal
 //   odd  step: left = the lane's own even diagonal,             up = lane m+1's even diagonal (DPP wave_shl:1)
-// The row scores (4 x int8 per base of seq1) and the column one-hots (seq2) are staged per alignment in LDS; they stream
-// through the lanes by one DPP shift per step, the new element entering at lane 0 / lane 63 from a broadcast LDS read.
+// The row scores (4 x int8 per base of seq1) and the column one-hots (seq2) are staged per alignment in LDS, with pad
+// entries either side; every lane reads the entry of its own row / column, one of each per two cells.
 // E and F are kept saturated at 0 (v_sub_u32 clamp): max(0, E) is all H ever needs, and it makes every out-of-band or
 // out-of-matrix neighbour (which the DPP shifts and the pad entries deliver as 0) behave as -infinity.  Cells past the end
 // of either sequence keep computing; their values are bounded by the running maximum (open, ext >= 0), so nothing is masked.
@@ -506,17 +506,18 @@ __device__ __forceinline__ int from_lane_above(int v)   // value of lane m+1, 0 
     return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 
+template <bool kOpenGeExt>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
                         uint32_t n, int len, SmRows rows, int gap_open, int gap_ext)
 {
-    extern __shared__ uint32_t lds_dyn[];       // per wave: row scores [len + 64] then column one-hots [len + 64]
+    extern __shared__ uint32_t lds_dyn[];       // per wave: row scores [len + 72] then column one-hots [len + 72], 32 pads in front
     __shared__ uint32_t lds_rows[kWavesPerBlock][4];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t pair = blockIdx.x * kWavesPerBlock + wv;
     if (pair >= n) return;                      // wave-uniform; only wave-level synchronisation below
-    const int stride = len + 64;
+    const int stride = len + 72;
     uint32_t *arow = lds_dyn + (size_t)wv * 2 * stride;
     uint32_t *boh = arow + stride;
 
@@ -526,29 +527,71 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint8_t *s1 = seq1s + (size_t)pair * (size_t)len;
     const uint8_t *s2 = seq2s + (size_t)pair * (size_t)len;
-    for (int k = lane; k < stride; k += 64) {
-        const bool in = k < len;
+    for (int kp = lane; kp < stride; kp += 64) {                // entry kp holds position kp - 32 of the sequence
+        const int k = kp - 32;
+        const bool in = (unsigned)k < (unsigned)len;
         const uint32_t a = in ? (s1[k] & 3u) : 0u;
         const uint32_t b = in ? (s2[k] & 3u) : 0u;
-        arow[k] = in ? lds_rows[wv][a] : 0x80808080u;     // pad rows score -128 against everything
-        boh[k] = in ? (1u << (8u * b)) : 0u;              // pad columns select nothing
+        arow[kp] = in ? lds_rows[wv][a] : 0x80808080u;    // pad rows score -128 against everything
+        boh[kp] = in ? (1u << (8u * b)) : 0u;             // pad columns select nothing
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // state at u = 0: lane m sits at row i = 33 - m, column j = m - 31
-    int a_cur = lane <= 32 ? (int)arow[32 - lane] : (int)0x80808080u;
-    int b_cur = lane >= 32 ? (int)boh[lane - 32] : 0;
+    // In iteration u lane m sits at row i = 33 - m + u (both steps) and column j = u + m - 31 (even step) / j + 1 (odd
+    // step), 1-based.  Each lane reads its own row scores and one-hots from LDS, one entry of each per iteration and one
+    // iteration ahead (the LDS pipe is otherwise idle; streaming them through the lanes cost one DPP move per cell).
+    const uint32_t *pa = arow + (64 - lane);    // pa[u] = row scores of row i
+    const uint32_t *pb = boh + lane;            // pb[u] = one-hot of column j, pb[u + 1] of column j + 1
+    int a_cur = (int)pa[0];
+    int b_cur = (int)pb[0];
+    int best = 0;
+
+    if constexpr (kOpenGeExt) {
+        // open >= ext (the usual case).  With hm = max(H - (open - ext), 0) both gap recurrences become
+        //   E = max(max(E_left, hm_left) - ext, 0),   F = max(max(F_up, hm_up) - ext, 0)
+        // (saturating subtraction distributes over max, and (H -sat (open-ext)) -sat ext = H -sat open), so a cell hands
+        // its neighbours ONE value each -- me = max(E, hm) to the right, mf = max(F, hm) downwards -- and one of the two
+        // crosses lanes: 1 DPP + 3 subtractions + 2 max + dot4 + max3 per cell.
+        const int oe = gap_open - gap_ext;
+        int h0 = 0, me0 = 0, mf0 = 0;           // last cell on the even diagonal 2m
+        int h1 = 0, me1 = 0, mf1 = 0;           // last cell on the odd diagonal 2m+1
+        for (int u = 0; u < len; ++u) {
+            const int b_next = (int)pb[u + 1];
+            const int a_next = (int)pa[u + 1];
+            {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
+                const int e = sat_sub<false>(from_lane_below(me1), gap_ext);
+                const int f = sat_sub<false>(mf1, gap_ext);
+                const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
+                const int tf = t > f ? t : f;
+                h0 = tf > e ? tf : e;           // v_max3_i32; >= 0 because e, f >= 0
+                const int hm = sat_sub<false>(h0, oe);
+                me0 = e > hm ? e : hm;
+                mf0 = f > hm ? f : hm;
+            }
+            b_cur = b_next;
+            {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
+                const int e = sat_sub<false>(me0, gap_ext);
+                const int f = sat_sub<false>(from_lane_above(mf0), gap_ext);
+                const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
+                const int tf = t > f ? t : f;
+                h1 = tf > e ? tf : e;
+                const int hm = sat_sub<false>(h1, oe);
+                me1 = e > hm ? e : hm;
+                mf1 = f > hm ? f : hm;
+            }
+            const int hb = h0 > h1 ? h0 : h1;
+            best = best > hb ? best : hb;
+            a_cur = a_next;
+        }
+    } else {
     int h0 = 0, e0 = 0, f0 = 0;                 // last cell on the even diagonal 2m
     int h1 = 0, e1 = 0, f1 = 0;                 // last cell on the odd diagonal 2m+1
-    int best = 0;
-    int b_in = (int)boh[32];                    // enters at lane 63 before the first odd step: column 33
-    int a_in = (int)arow[33];                   // enters at lane 0 before the second even step: row 34
 
     for (int u = 0; u < len; ++u) {
-        const int b_in_next = (int)boh[u + 33];
-        const int a_in_next = (int)arow[u + 34 < stride ? u + 34 : stride - 1];
+        const int b_next = (int)pb[u + 1];
+        const int a_next = (int)pa[u + 1];
         // even step: diagonal 2m, cell (i, j)
         {
             const int hl = from_lane_below(h1), el = from_lane_below(e1);
@@ -560,8 +603,7 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
             e0 = e;
             f0 = f;
         }
-        // the column stream advances: lane m takes lane m+1's one-hot, lane 63 the next column of seq2
-        b_cur = __builtin_amdgcn_update_dpp(b_in, b_cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        b_cur = b_next;
         // odd step: diagonal 2m+1, cell (i, j+1)
         {
             const int hu = from_lane_above(h0), fu = from_lane_above(f0);
@@ -575,10 +617,8 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
         }
         const int hb = h0 > h1 ? h0 : h1;
         best = best > hb ? best : hb;
-        // the row stream advances: lane m takes lane m-1's row scores, lane 0 the next row of seq1
-        a_cur = __builtin_amdgcn_update_dpp(a_in, a_cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        b_in = b_in_next;
-        a_in = a_in_next;
+        a_cur = a_next;
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -702,9 +742,13 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
     if (n == 0) return hipSuccess;
     const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 64) * sizeof(uint32_t);
-    hipLaunchKernelGGL(sw_banded_affine_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, d_seq1s,
-                       d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 72) * sizeof(uint32_t);
+    if (gap_open >= gap_ext)
+        hipLaunchKernelGGL(sw_banded_affine_kernel<true>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream,
+                           d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    else
+        hipLaunchKernelGGL(sw_banded_affine_kernel<false>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream,
+                           d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
     return hipGetLastError();
 }
 

@@ -89,7 +89,8 @@ def test_gpu_banded_affine_matches_the_oracle(gpu, oracle, length):
     shift = np.roll(a[-8:], 70, axis=1)                                       # offset beyond the band
     b[-8:] = shift
     for sm, go, ge in ((match_matrix(2, -3), 5, 1), (match_matrix(10, -30), 15, 15), (match_matrix(1, -1), 0, 0),
-                       (match_matrix(127, -127), 127, 0), (rng.integers(-128, 128, 16).astype(np.int8), 11, 3)):
+                       (match_matrix(127, -127), 127, 0), (rng.integers(-128, 128, 16).astype(np.int8), 11, 3),
+                       (match_matrix(2, -3), 1, 4), (match_matrix(5, -4), 0, 7)):      # open < extend: the other kernel body
         got = gpu.score_banded_affine(a, b, sm, go, ge)
         want = oracle.banded_affine(a, b, sm, go, ge)
         assert np.array_equal(got, want), (length, go, ge, int((got != want).sum()))
