@@ -4,14 +4,15 @@
 //
 // Not a translation of the AVX2 variants (one 32-byte vector per anti-diagonal, u8 cells re-based every round,
 // source.cpp:2099-2109).  Here:
-//   * forward sweep: 32 lanes = the 32 cells of the band (BANDWIDTH, source.cpp:1848), two alignments per wavefront; cell values stay int32 with the
-//     reference's +70 offset (0 = dropped).  The band's direction (right / down) is decided per alignment every round
-//     from its two end lanes; the shifted neighbours come from cross-lane reads.  Instead of the reference's 4 MB table
-//     of cell values per alignment (source.cpp:1876) the sweep stores, per round, only what the traceback needs:
-//     a 2-bit predecessor code per lane (diag / up / left in the reference's own tie-break order :1962-1971) and the row
-//     of the band's top lane -- 10 bytes per round instead of 128.
-//   * traceback: one thread per alignment follows the codes back to (0,0) (twice: once to count, once to emit the
-//     positions in ascending order, as the reference returns them).
+//   * forward sweep: the 32 cells of the band (BANDWIDTH, source.cpp:1848) live in 32 lanes (sg_forward_kernel, small
+//     batches) or in 4 / 2 lanes with 8 / 16 cells each (sg_forward_split_kernel, large batches); cell values stay int32.
+//     The band's direction (right / down) is decided per alignment every round from its two end cells (:1895).  Instead
+//     of the reference's 4 MB table of cell values per alignment (source.cpp:1876) the sweep stores, per round, only what
+//     the traceback needs: a 2-bit predecessor code per cell (diag / up / left in the reference's own tie-break order
+//     :1962-1971) and the row of the band's top cell -- 10 bytes per round instead of 128.
+//   * traceback: follows the codes from the best cell back to (0,0) and returns the positions in ascending order, as the
+//     reference does (:1951-1975): one wavefront per walk (sg_traceback_kernel, small batches) or one lane per walk that
+//     records its moves + a prefix-sum kernel that expands them (sg_walk_lane_kernel, sg_expand_kernel, large batches).
 #include "swmi_internal.h"
 
 #include <cstdlib>
