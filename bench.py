@@ -312,6 +312,7 @@ def main():
     if args.lanes:
         swmi.set_schedule(args.lanes, 0)
     lanes, flags = swmi.get_schedule()
+    lanes = lanes or swmi.schedule_for_batch(args.pairs)      # 0 = automatic: what it resolves to for this batch size
     if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)

@@ -42,6 +42,7 @@ constexpr size_t kSeq = SWMI_SEQ_LEN;
 constexpr size_t kChunkPairs = size_t(1) << 20;      // host-batch pipeline granule: 1M pairs = 128 MiB per input array
 constexpr size_t kMaxLaunchPairs = size_t(1) << 30;  // pairs per kernel launch (kernel indexes pairs with uint32)
 constexpr int kSlots = 2;
+constexpr size_t kPinPairs = 64;        // host batches up to this size go through the pinned staging buffer
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -56,11 +57,15 @@ struct Context {
     hipDeviceProp_t prop{};
     hipStream_t stream = nullptr;       // library-owned stream (host-side helpers)
     Slot slots[kSlots];
-    int lanes = 4;                      // default schedule
+    int lanes = 0;                      // 0 = automatic: by batch size (auto_lanes)
     unsigned flags = 0;
     void *sg_workspace = nullptr;       // semi-global aligner workspace (device), grown on demand
     size_t sg_workspace_bytes = 0;
     unsigned extra_lds = 0;             // SWMI_EXTRA_LDS: occupancy sweep knob (BASELINE config 3)
+    // pinned, device-visible staging for tiny host batches (the per-pair call): the kernel reads the pairs from host
+    // memory and writes the scores back there, so a call is one launch + one synchronisation, no copies
+    uint8_t *pin = nullptr;             // [kPinPairs * 128] seq1s, [kPinPairs * 128] seq2s, [kPinPairs] int32 scores
+    void *pin_dev = nullptr;            // the same memory as the device sees it
     std::mutex mu;                      // serialises use of the slots
 };
 
@@ -92,11 +97,19 @@ SmRows pack_rows(const int8_t *sm, int add)
     return rows;
 }
 
-// Choose the cell body: the gap-folded recurrence needs every sm + gap to fit int8.
-LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows)
+// Lanes per alignment when the caller has not fixed a schedule: L = 4 (32 rows per lane) issues the fewest instructions
+// per cell and wins once the batch fills the chip; a small batch wants many lanes per alignment instead -- a single pair
+// takes 6 us with L = 64 and 42 us with L = 4 (tools/small_batch_schedule.py, profiles/r01_small_batch_schedule.txt).
+int auto_lanes(size_t n)
+{
+    return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 20480 ? 16 : 4;
+}
+
+// Choose the schedule and the cell body: the gap-folded recurrence needs every sm + gap to fit int8.
+LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows, size_t n)
 {
     LaunchConfig cfg;
-    cfg.lanes_per_alignment = g_ctx.lanes;
+    cfg.lanes_per_alignment = g_ctx.lanes ? g_ctx.lanes : (g_ctx.flags & swmi::kUseLut) ? 4 : auto_lanes(n);
     cfg.use_i16 = (g_ctx.flags & swmi::kUseI16) != 0;
     cfg.use_lut = (g_ctx.flags & swmi::kUseLut) != 0;
     cfg.extra_lds_bytes = g_ctx.extra_lds;
@@ -128,7 +141,7 @@ int launch_device(const void *d1, const void *d2, size_t n, const int8_t *sm, in
                   bool packed)
 {
     SmRows rows;
-    const LaunchConfig cfg = make_config(sm, gap, &rows);
+    const LaunchConfig cfg = make_config(sm, gap, &rows, n);
     const size_t stride = packed ? SWMI_PACKED_LEN : kSeq;
     for (size_t off = 0; off < n; off += kMaxLaunchPairs) {
         const size_t m = n - off < kMaxLaunchPairs ? n - off : kMaxLaunchPairs;
@@ -147,7 +160,7 @@ int score_host_batch(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_
     const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
     const size_t chunk = n < kChunkPairs ? n : kChunkPairs;
     SmRows rows;
-    const LaunchConfig cfg = make_config(sm, gap, &rows);
+    const LaunchConfig cfg = make_config(sm, gap, &rows, chunk);
     for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
         const int rc = ensure_slot(g_ctx.slots[k], chunk);
         if (rc != SWMI_OK) return rc;
@@ -238,6 +251,8 @@ int swmi_init(int device)
     HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     for (auto &s : g_ctx.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     g_ctx.device = device;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_ctx.pin), kPinPairs * (2 * kSeq + sizeof(int32_t)), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(&g_ctx.pin_dev, g_ctx.pin, 0));
     const char *env_x = getenv("SWMI_EXTRA_LDS");
     g_ctx.extra_lds = env_x ? (unsigned)atoi(env_x) : 0;
     const char *env_l = getenv("SWMI_LANES");
@@ -264,6 +279,9 @@ int swmi_shutdown(void)
     if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
     g_ctx.sg_workspace = nullptr;
     g_ctx.sg_workspace_bytes = 0;
+    if (g_ctx.pin) (void)hipHostFree(g_ctx.pin);
+    g_ctx.pin = nullptr;
+    g_ctx.pin_dev = nullptr;
     g_ctx.ready = false;
     g_ctx.device = -1;
     return SWMI_OK;
@@ -271,8 +289,7 @@ int swmi_shutdown(void)
 
 int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
 {
-    if (lanes_per_alignment == 0) lanes_per_alignment = 4;
-    if (!swmi::schedule_supported(lanes_per_alignment))
+    if (lanes_per_alignment != 0 && !swmi::schedule_supported(lanes_per_alignment))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
     if (flags & ~7u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
     g_ctx.lanes = lanes_per_alignment;
@@ -282,9 +299,14 @@ int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
 
 int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags)
 {
-    if (lanes_per_alignment) *lanes_per_alignment = g_ctx.lanes;
+    if (lanes_per_alignment) *lanes_per_alignment = g_ctx.lanes;      // 0 = automatic
     if (flags) *flags = g_ctx.flags;
     return SWMI_OK;
+}
+
+int swmi_schedule_for_batch(size_t n)
+{
+    return g_ctx.lanes ? g_ctx.lanes : (g_ctx.flags & swmi::kUseLut) ? 4 : auto_lanes(n);
 }
 
 int swmi_get_device_info(swmi_device_info *info)
@@ -313,6 +335,19 @@ int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, const
     rc = check_ready();
     if (rc != SWMI_OK) return rc;
     HIP_TRY(hipSetDevice(g_ctx.device));
+    if (n <= kPinPairs) {               // the per-pair call and its small relatives: no copies, one launch, one wait
+        std::lock_guard<std::mutex> lock(g_ctx.mu);
+        uint8_t *h1 = g_ctx.pin, *h2 = g_ctx.pin + kPinPairs * kSeq;
+        int32_t *hs = reinterpret_cast<int32_t *>(g_ctx.pin + 2 * kPinPairs * kSeq);
+        uint8_t *dev = static_cast<uint8_t *>(g_ctx.pin_dev);
+        memcpy(h1, seq1s, n * kSeq);
+        memcpy(h2, seq2s, n * kSeq);
+        rc = launch_device(dev, dev + kPinPairs * kSeq, n, score_matrix, gap_penalty, dev + 2 * kPinPairs * kSeq, g_ctx.stream, false);
+        if (rc != SWMI_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        memcpy(scores, hs, n * sizeof(int32_t));
+        return SWMI_OK;
+    }
     return score_host_batch(seq1s, seq2s, n, score_matrix, gap_penalty, scores, false, false);
 }
 
@@ -349,7 +384,7 @@ int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void
     rc = check_ready();
     if (rc != SWMI_OK) return rc;
     SmRows rows;
-    const LaunchConfig cfg = make_config(score_matrix, gap_penalty, &rows);
+    const LaunchConfig cfg = make_config(score_matrix, gap_penalty, &rows, n_seq1);
     for (size_t off = 0; off < n_seq1; off += kMaxLaunchPairs) {
         const size_t m = n_seq1 - off < kMaxLaunchPairs ? n_seq1 - off : kMaxLaunchPairs;
         HIP_TRY(swmi::launch_score_one_vs_many(cfg, static_cast<const uint8_t *>(d_seq1s) + off * kSeq,

@@ -68,6 +68,7 @@ def load():
     lib.swmi_unpack.argtypes = [vp, sz, vp]
     lib.swmi_semiglobal_xdrop.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.swmi_semiglobal_xdrop_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    lib.swmi_schedule_for_batch.argtypes = [sz]
     lib.swmi_semiglobal_time_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
     lib.swmi_score_banded_affine_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
@@ -134,6 +135,11 @@ def get_schedule():
     lanes, flags = ctypes.c_int(), ctypes.c_uint()
     _check(load().swmi_get_schedule(ctypes.byref(lanes), ctypes.byref(flags)))
     return lanes.value, flags.value
+
+
+def schedule_for_batch(n):
+    """Lanes per alignment a launch of n pairs runs with (what the automatic setting resolves to)."""
+    return int(load().swmi_schedule_for_batch(ctypes.c_size_t(n)))
 
 
 def device_info():
