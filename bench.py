@@ -197,6 +197,18 @@ def bench_banded(args, swmi, np, torch, local_rank):
     return 0
 
 
+def sg_traffic(P, kernel):
+    """HBM bytes per launch of the sweep kernel from the committed PMC passes (65536 alignments), or None."""
+    f = os.path.join(ROOT, "profiles", "r01_semiglobal_pmc.json")
+    if P != 65536 or not os.path.exists(f):
+        return None
+    try:
+        k = json.load(open(f)).get(kernel, {})
+        return int(k["hbm_read_bytes_x2"] + k["hbm_write_bytes"])
+    except Exception:
+        return None
+
+
 def bench_semiglobal(args, swmi, np, torch, local_rank):
     """Secondary row: the reference's semi-global adaptive-band X-drop aligner incl. traceback (single GPU).
     Inputs follow SpeedtestSemiGlobal (source.cpp:2805-2813): a random 16384-mer and a copy with 5 % substitutions."""
@@ -245,13 +257,16 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     rounds, ops_cell = 32768, 9
     sweep_ops = P * rounds * 32 * ops_cell
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
+    sweep_kernel = "sg_forward_split_kernel<2>" if P >= 98304 else "sg_forward_split_kernel<4>" if P >= 6144 else "sg_forward_kernel"
     line["roofline"] = {
-        "bound": "valu", "kernel": "sg_forward_split_kernel<2>" if P >= 98304 else "sg_forward_split_kernel<4>" if P >= 6144 else "sg_forward_kernel",
+        "bound": "valu", "kernel": sweep_kernel,
         "kernel_ms": round(sweep_ms, 3), "achieved": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),
         "peak": round(VALU_PEAK_TOPS, 1), "unit": "TOP/s (int32)",
         "frac": round(sweep_ops / (sweep_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
         "algorithmic_ops_per_launch": sweep_ops, "gcups_kernel": round(P * rounds * 32 / (sweep_ms * 1e-3) / 1e9, 1),
-        "traffic": None,
+        "traffic": sg_traffic(P, sweep_kernel),
+        "traffic_source": "profiles/r01_semiglobal_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the sweep kernel, separate passes; "
+                          "the records leave in 64-byte pieces of 128-byte L2 lines, hence the read-for-ownership traffic)",
         "kernel_ms_covers": "sweep phase between HIP events: the stream-packing pre-pass (~0.6 ms at 65536) + the sweep kernel",
         "traceback_kernel_ms": round(tb_ms, 3),
         "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / ((sweep_ms + tb_ms) * 1e-3) / 1e9, 1),
