@@ -139,7 +139,9 @@ SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_
  * X-drop 70, result = (score, traceback).  scores[k] = .first; tracebacks + k*cap*2 receives the (i, j) pairs of
  * .second in the reference's order (from (0,0) to the best cell), at most `cap` of them; lengths[k] = .second.size()
  * (<= 32769).  Host buffers.  Where the reference reads one byte past its padded sequences (the band at the very
- * last position, source.cpp:1917-1919) this implementation reads a pad. */
+ * last position, source.cpp:1917-1919) this implementation reads a pad.  Bases must be 0..3: the reference's sweep scores
+ * any other byte as a mismatch against everything (:1918-1920) but its traceback indexes the 4x4 matrix with it (:1961,
+ * out of range); here such a byte is a mismatch against everything in both. */
 #define SWMI_SG_LEN 16384
 #define SWMI_SG_MAX_TRACEBACK 32769
 SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,

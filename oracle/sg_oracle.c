@@ -125,7 +125,9 @@ int sg_oracle_xdrop(const uint8_t *seq1, const uint8_t *seq2, int32_t *score, in
     tmp[0] = (int32_t)y; tmp[1] = (int32_t)x; n = 1;
     while (y || x) {
         const int v = sg_get(&t, y, x);
-        if (y && x && v == sg_get(&t, y - 1, x - 1) + ((seq1[y - 1] == seq2[x - 1]) ? 1 : -1) && sg_get(&t, y - 1, x - 1) > 0) { --y; --x; }
+        /* the reference indexes its 4x4 matrix with the raw bytes here (source.cpp:1961): undefined for a byte >= 4.  Such
+         * bytes are outside its domain; this restatement gives them the sweep's meaning (mismatch against everything). */
+        if (y && x && v == sg_get(&t, y - 1, x - 1) + ((seq1[y - 1] < 4 && seq1[y - 1] == seq2[x - 1]) ? 1 : -1) && sg_get(&t, y - 1, x - 1) > 0) { --y; --x; }
         else if (y && v == sg_get(&t, y - 1, x) - 1 && sg_get(&t, y - 1, x) > 0) { --y; }
         else if (x && v == sg_get(&t, y, x - 1) - 1 && sg_get(&t, y, x - 1) > 0) { --x; }
         else { free(tmp); free(t.cell); free(t.top_y); return -2; }   /* the reference asserts here */

@@ -169,10 +169,15 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
     unsigned long long out;
     if (j < (uint32_t)(kLen / 16)) {
         const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * j);
-        auto squeeze = [](unsigned v) -> unsigned long long {             // 4 bytes (0..3 each) -> 4 fields
-            v &= 0x03030303u;
-            v = (v | (v >> 4)) & 0x00FF00FFu;
-            return (unsigned long long)((v | (v >> 8)) & 0xFFFFu);
+        const unsigned pad = second ? 4u : 8u;
+        auto squeeze = [pad](unsigned v) -> unsigned long long {          // 4 bytes -> 4 fields
+            unsigned r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned b = (v >> (8 * k)) & 0xFFu;
+                r |= (b < 4u ? b : pad) << (4 * k);       // a byte that is no base scores as a mismatch against anything
+            }                                             // (source.cpp:1918-1920), which is what a pad field does
+            return (unsigned long long)r;
         };
         out = squeeze(b.x) | (squeeze(b.y) << 16) | (squeeze(b.z) << 32) | (squeeze(b.w) << 48);
     } else {

@@ -139,3 +139,25 @@ def test_gpu_semiglobal_host_entry_pipelines_chunks(gpu, oracle):
     assert np.array_equal(lengths, np.array([len(want[k][1]) for k in pick], np.uint32))
     for j in range(0, n, 97):
         assert np.array_equal(tbs[j], want[pick[j]][1][:cap]), j
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1)])
+def test_gpu_semiglobal_bytes_that_are_no_base(gpu, oracle, sg_kernels, sweep, traceback):
+    """Outside the reference's domain (its traceback indexes the 4x4 matrix with the raw byte, source.cpp:1961), but defined
+    here: a byte >= 4 scores as a mismatch against everything, also against itself -- the meaning the reference's sweep
+    gives it (:1918-1920).  Oracle and every GPU mapping agree."""
+    sg_kernels(sweep, traceback)
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 4, (3, 16384), dtype=np.uint8)
+    b = a.copy()
+    for k in range(3):
+        idx = rng.integers(0, 16384, 300)
+        b[k, idx] = rng.integers(0, 4, 300, dtype=np.uint8)
+    a[0, 1000:1010] = 4                     # an N-run in seq1 only
+    b[1, 5000:5003] = 255                   # junk bytes in seq2 only
+    a[2, 7000:7004] = 9; b[2, 7000:7004] = 9   # the same non-base in both: still a mismatch
+    scores, tbs, lengths = gpu.semiglobal_xdrop(a, b)
+    for k in range(3):
+        want_score, want_tb = oracle.semiglobal(a[k], b[k])
+        assert int(scores[k]) == want_score and np.array_equal(tbs[k], want_tb), k
