@@ -88,5 +88,17 @@ def test_bases_modulo_4_like_the_oracle(gpu, oracle):
     a = rng.integers(0, 256, (512, 128), dtype=np.uint8)
     b = rng.integers(0, 256, (512, 128), dtype=np.uint8)
     sm = match_matrix(4, -5)
-    assert np.array_equal(gpu.score_batch(a, b, sm, 3), oracle.batch(a, b, sm, 3))
+    want = oracle.batch(a, b, sm, 3)
+    assert np.array_equal(gpu.score_batch(a, b, sm, 3), want)
     assert np.array_equal(gpu.score_batch(a, b, sm, 3), gpu.score_batch(a & 3, b & 3, sm, 3))
+    try:                                                    # every schedule and cell body, and the sibling entry points
+        for lanes in (64, 32, 16, 8, 4, 2):
+            for flags in (0, 1, 2) + ((4,) if lanes in (16, 8, 4) else ()):
+                gpu.set_schedule(lanes, flags)
+                assert np.array_equal(gpu.score_batch(a, b, sm, 3), want), (lanes, flags)
+    finally:
+        gpu.set_schedule(0, 0)
+    assert np.array_equal(gpu.score_one_vs_many(a, b[0], sm, 3), oracle.batch(a, np.broadcast_to(b[0], a.shape).copy(), sm, 3))
+    a1 = rng.integers(0, 256, (16, 256), dtype=np.uint8)
+    b1 = rng.integers(0, 256, (16, 256), dtype=np.uint8)
+    assert np.array_equal(gpu.score_banded_affine(a1, b1, sm, 6, 2), oracle.banded_affine(a1 & 3, b1 & 3, sm, 6, 2))
