@@ -161,3 +161,23 @@ def test_gpu_semiglobal_bytes_that_are_no_base(gpu, oracle, sg_kernels, sweep, t
     for k in range(3):
         want_score, want_tb = oracle.semiglobal(a[k], b[k])
         assert int(scores[k]) == want_score and np.array_equal(tbs[k], want_tb), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1)])
+def test_gpu_semiglobal_scores_only(gpu, oracle, sg_kernels, sweep, traceback):
+    """cap = 0: scores and path lengths without any positions (the traceback buffer may be absent)."""
+    sg_kernels(sweep, traceback)
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 4, (5, 16384), dtype=np.uint8)
+    b = a.copy()
+    b[:, ::29] = rng.integers(0, 4, b[:, ::29].shape, dtype=np.uint8)
+    b[4] = rng.integers(0, 4, 16384, dtype=np.uint8)                # unrelated: drops out early
+    import ctypes
+    scores = np.zeros(5, np.int32)
+    lengths = np.zeros(5, np.uint32)
+    rc = gpu.load().swmi_semiglobal_xdrop(a.ctypes.data, b.ctypes.data, 5, scores.ctypes.data, None, 0, lengths.ctypes.data)
+    assert rc == 0, gpu.last_error()
+    for k in range(5):
+        want_score, want_tb = oracle.semiglobal(a[k], b[k])
+        assert int(scores[k]) == want_score and int(lengths[k]) == len(want_tb), k
