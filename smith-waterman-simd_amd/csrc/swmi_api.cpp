@@ -64,6 +64,15 @@ struct Context {
     unsigned extra_lds = 0;             // SWMI_EXTRA_LDS: occupancy sweep knob (BASELINE config 3)
     // pinned, device-visible staging for tiny host batches (the per-pair call): the kernel reads the pairs from host
     // memory and writes the scores back there, so a call is one launch + one synchronisation, no copies
+    // device buffers of the host-buffer semi-global entry (two chunks in flight), kept between calls and grown on demand
+    struct SgSet {
+        uint8_t *d1 = nullptr, *d2 = nullptr;
+        void *ws = nullptr;
+        int32_t *d_scores = nullptr, *d_tb = nullptr;
+        uint32_t *d_len = nullptr;
+        size_t alignments = 0, tb_entries = 0;      // capacity
+        size_t off = 0, m = 0;                      // chunk in flight
+    } sg_sets[2];
     uint8_t *pin = nullptr;             // [kPinPairs * 128] seq1s, [kPinPairs * 128] seq2s, [kPinPairs] int32 scores
     void *pin_dev = nullptr;            // the same memory as the device sees it
     std::mutex mu;                      // serialises use of the slots
@@ -279,6 +288,10 @@ int swmi_shutdown(void)
     if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
     g_ctx.sg_workspace = nullptr;
     g_ctx.sg_workspace_bytes = 0;
+    for (auto &g : g_ctx.sg_sets) {
+        (void)hipFree(g.d1); (void)hipFree(g.d2); (void)hipFree(g.ws); (void)hipFree(g.d_scores); (void)hipFree(g.d_len); (void)hipFree(g.d_tb);
+        g = Context::SgSet{};
+    }
     if (g_ctx.pin) (void)hipHostFree(g_ctx.pin);
     g_ctx.pin = nullptr;
     g_ctx.pin_dev = nullptr;
@@ -568,61 +581,70 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     // Chunks of up to 8192 alignments (~0.35 MB of workspace + cap*8 B of output each), two sets of device buffers: while
     // the host is busy receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k+1.
     const size_t chunk = n < 8192 ? n : 8192;
-    struct Set {
-        uint8_t *d1 = nullptr, *d2 = nullptr;
-        void *ws = nullptr;
-        int32_t *d_scores = nullptr, *d_tb = nullptr;
-        uint32_t *d_len = nullptr;
-        hipStream_t st = nullptr;
-        size_t off = 0, m = 0;
-    } sets[2];
+    using Set = Context::SgSet;
+    Set *sets = g_ctx.sg_sets;
     const int n_sets = n > chunk ? 2 : 1;
+    hipStream_t streams[2] = {g_ctx.slots[0].stream, g_ctx.slots[1].stream};
     hipError_t e = hipSuccess;
     for (int k = 0; k < n_sets && e == hipSuccess; ++k) {
         Set &s = sets[k];
-        s.st = g_ctx.slots[k].stream;
-        e = hipMalloc(&s.d1, chunk * kLen);
-        if (e == hipSuccess) e = hipMalloc(&s.d2, chunk * kLen);
-        if (e == hipSuccess) e = hipMalloc(&s.ws, swmi::semiglobal_workspace_bytes(chunk));
-        if (e == hipSuccess) e = hipMalloc(&s.d_scores, chunk * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&s.d_len, chunk * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&s.d_tb, (chunk * (cap ? cap : 1)) * 2 * sizeof(int32_t));
+        s.off = s.m = 0;
+        const size_t tb_need = chunk * (cap ? cap : 1);
+        if (s.alignments < chunk) {
+            (void)hipFree(s.d1); (void)hipFree(s.d2); (void)hipFree(s.ws); (void)hipFree(s.d_scores); (void)hipFree(s.d_len);
+            s.d1 = s.d2 = nullptr; s.ws = nullptr; s.d_scores = nullptr; s.d_len = nullptr; s.alignments = 0;
+            e = hipMalloc(&s.d1, chunk * kLen);
+            if (e == hipSuccess) e = hipMalloc(&s.d2, chunk * kLen);
+            if (e == hipSuccess) e = hipMalloc(&s.ws, swmi::semiglobal_workspace_bytes(chunk));
+            if (e == hipSuccess) e = hipMalloc(&s.d_scores, chunk * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&s.d_len, chunk * sizeof(uint32_t));
+            if (e == hipSuccess) s.alignments = chunk;
+        }
+        if (e == hipSuccess && s.tb_entries < tb_need) {
+            (void)hipFree(s.d_tb);
+            s.d_tb = nullptr; s.tb_entries = 0;
+            e = hipMalloc(&s.d_tb, tb_need * 2 * sizeof(int32_t));
+            if (e == hipSuccess) s.tb_entries = tb_need;
+        }
     }
     // results of the chunk a set holds -> host; only as many positions per alignment as the longest path of the chunk has
-    auto drain = [&](Set &s) -> hipError_t {
+    auto drain = [&](int which) -> hipError_t {
+        Set &s = sets[which];
+        hipStream_t st = streams[which];
         if (s.m == 0) return hipSuccess;
-        hipError_t r = hipMemcpyAsync(scores + s.off, s.d_scores, s.m * sizeof(int32_t), hipMemcpyDeviceToHost, s.st);
-        if (r == hipSuccess) r = hipMemcpyAsync(lengths + s.off, s.d_len, s.m * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st);
-        if (r == hipSuccess) r = hipStreamSynchronize(s.st);
+        hipError_t r = hipMemcpyAsync(scores + s.off, s.d_scores, s.m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipMemcpyAsync(lengths + s.off, s.d_len, s.m * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r == hipSuccess && cap) {
             size_t longest = 0;
             for (size_t k = 0; k < s.m; ++k) longest = lengths[s.off + k] > longest ? lengths[s.off + k] : longest;
             if (longest > cap) longest = cap;
             const size_t pitch = cap * 2 * sizeof(int32_t);
             r = hipMemcpy2DAsync(tracebacks + s.off * cap * 2, pitch, s.d_tb, pitch, longest * 2 * sizeof(int32_t), s.m,
-                                 hipMemcpyDeviceToHost, s.st);
-            if (r == hipSuccess) r = hipStreamSynchronize(s.st);
+                                 hipMemcpyDeviceToHost, st);
+            if (r == hipSuccess) r = hipStreamSynchronize(st);
         }
         s.m = 0;
         return r;
     };
     int turn = 0;
     for (size_t off = 0; e == hipSuccess && off < n; off += chunk, turn ^= 1) {
-        Set &s = sets[n_sets == 2 ? turn : 0];
-        e = drain(s);                                       // (two chunks ago; normally already empty)
+        const int which = n_sets == 2 ? turn : 0;
+        Set &s = sets[which];
+        hipStream_t st = streams[which];
+        e = drain(which);                                   // (two chunks ago; normally already empty)
         if (e != hipSuccess) break;
         s.off = off;
         s.m = n - off < chunk ? n - off : chunk;
-        e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, s.st);
-        if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, s.st);
-        if (e == hipSuccess) e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, s.st);
-        if (e == hipSuccess && n_sets == 2) e = drain(sets[turn ^ 1]);   // the previous chunk, while this one computes
+        e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st);
+        if (e == hipSuccess && n_sets == 2) e = drain(turn ^ 1);         // the previous chunk, while this one computes
     }
     for (int k = 0; k < n_sets; ++k) {
-        if (e == hipSuccess) e = drain(sets[k]);
-        Set &s = sets[k];
-        if (e != hipSuccess && s.st) (void)hipStreamSynchronize(s.st);
-        (void)hipFree(s.d1); (void)hipFree(s.d2); (void)hipFree(s.ws); (void)hipFree(s.d_scores); (void)hipFree(s.d_len); (void)hipFree(s.d_tb);
+        if (e == hipSuccess) e = drain(k);
+        if (e != hipSuccess) (void)hipStreamSynchronize(streams[k]);
+        sets[k].m = 0;
     }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_semiglobal_xdrop: %s", hipGetErrorString(e));
     return SWMI_OK;

@@ -33,6 +33,7 @@ int main(int argc, char **argv)
 {
     const size_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000;   // calls (reference: 1,000,000)
     const size_t n_sync = argc > 2 ? strtoull(argv[2], nullptr, 10) : 20000; // per-pair synchronous calls to time
+    // argv[3]: alignments in the SpeedtestSemiGlobal section (reference: 10,000)
     if (swmi_init(-1) != SWMI_OK) die("swmi_init");
     swmi_device_info info;
     swmi_get_device_info(&info);
@@ -115,6 +116,53 @@ int main(int argc, char **argv)
                    n / 1e6, n / ms / 1e3, n * 16384.0 / ms / 1e9);
             (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(ds);
         }
+    }
+    // == SpeedtestSemiGlobal (source.cpp:2804-2860): ONE pair of 16384-mers, 5 % substitutions (:2808-2812), aligned 10K
+    // times with score + traceback.  Here the 10K calls are one batch of 10K copies of that pair.
+    {
+        const size_t n_sg = argc > 3 ? strtoull(argv[3], nullptr, 10) : 10000;
+        constexpr size_t kLen = SWMI_SG_LEN, kCap = SWMI_SG_MAX_TRACEBACK;
+        std::vector<uint8_t> one_a(kLen), one_b(kLen);
+        {   // 16384 bases = 128 consecutive 128-mers of the generator; every 20th position of b redrawn (dice(rnd) == 0)
+            std::vector<uint8_t> g1(kLen), g2(kLen), g3(kLen), g4(kLen);
+            swmi_generate_pairs_host(g1.data(), g2.data(), kLen / 128, 10000, 0);
+            swmi_generate_pairs_host(g3.data(), g4.data(), kLen / 128, 10001, 0);
+            for (size_t i = 0; i < kLen; ++i) {
+                one_a[i] = g1[i];
+                one_b[i] = ((g3[i] * 4u + g4[i]) * 7u + i) % 20u == 0 ? g2[i] : g1[i];
+            }
+        }
+        printf("== SpeedtestSemiGlobal (16384 x 16384, band 32, X-drop 70, score + traceback)\n");
+        std::vector<uint8_t> s1(n_sg * kLen), s2(n_sg * kLen);
+        for (size_t k = 0; k < n_sg; ++k) {
+            memcpy(&s1[k * kLen], one_a.data(), kLen);
+            memcpy(&s2[k * kLen], one_b.data(), kLen);
+        }
+        std::vector<int32_t> scores(n_sg), tb(n_sg * kCap * 2);
+        std::vector<uint32_t> lengths(n_sg);
+        if (swmi_semiglobal_xdrop(s1.data(), s2.data(), n_sg, scores.data(), tb.data(), kCap, lengths.data()) != SWMI_OK)
+            die("swmi_semiglobal_xdrop");     // first call: device buffers are allocated (and kept)
+        const double t0 = now_ms();
+        if (swmi_semiglobal_xdrop(s1.data(), s2.data(), n_sg, scores.data(), tb.data(), kCap, lengths.data()) != SWMI_OK)
+            die("swmi_semiglobal_xdrop");
+        const double ms = now_ms() - t0;
+        printf("mi355x batch version: %.0f ms / %zuK incl. PCIe  (score %d, %u traceback positions, %.1f k alignments/s)\n", ms,
+               n_sg / 1000, scores[0], lengths[0], n_sg / ms);
+        void *d1 = nullptr, *d2 = nullptr, *dsc = nullptr, *dlen = nullptr, *dtb = nullptr;
+        if (hipMalloc(&d1, n_sg * kLen) != hipSuccess || hipMalloc(&d2, n_sg * kLen) != hipSuccess ||
+            hipMalloc(&dsc, n_sg * 4) != hipSuccess || hipMalloc(&dlen, n_sg * 4) != hipSuccess ||
+            hipMalloc(&dtb, n_sg * kCap * 8) != hipSuccess) {
+            fprintf(stderr, "hipMalloc failed\n");
+            return 1;
+        }
+        (void)hipMemcpy(d1, s1.data(), n_sg * kLen, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d2, s2.data(), n_sg * kLen, hipMemcpyHostToDevice);
+        float phase[2] = {0.f, 0.f};
+        if (swmi_semiglobal_time_device(d1, d2, n_sg, dsc, dtb, kCap, dlen, nullptr, phase) != SWMI_OK) die("warmup");
+        if (swmi_semiglobal_time_device(d1, d2, n_sg, dsc, dtb, kCap, dlen, nullptr, phase) != SWMI_OK) die("swmi_semiglobal_time_device");
+        printf("mi355x device version: %.1f ms / %zuK  (sweep %.1f + traceback %.1f ms, %.1f k alignments/s, inputs resident in HBM)\n",
+               phase[0] + phase[1], n_sg / 1000, phase[0], phase[1], n_sg / (phase[0] + phase[1]));
+        (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dsc); (void)hipFree(dlen); (void)hipFree(dtb);
     }
     swmi_shutdown();
     return 0;
