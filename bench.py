@@ -364,10 +364,12 @@ def main():
     d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
     p1 = p2 = None
-    # two score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernel of step k+1
-    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2 if collective else 1)]
-    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(2)] if collective else scores
-    pending = [None, None]
+    # a ring of score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernels of the
+    # following steps; four deep, so that a gather that gets its compute units late does not hold up the next launch
+    nbuf = 4 if collective else 1
+    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(nbuf)] if collective else scores
+    pending = [None] * nbuf
     stream = torch.cuda.current_stream()
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
     sm = swmi.match_matrix(args.match, args.mismatch)
@@ -388,7 +390,7 @@ def main():
     def step(k, ev=None):
         buf = k % len(scores)
         if pending[buf] is not None:
-            pending[buf].wait()                 # stream-side wait: the gather that read scores[buf] two steps ago is done
+            pending[buf].wait()                 # stream-side wait: the gather that read scores[buf] nbuf steps ago is done
         if ev is not None:
             ev[0].record(stream)
         launch(scores[buf].data_ptr())
