@@ -330,6 +330,9 @@ def main():
     lanes = lanes or swmi.schedule_for_batch(args.pairs)      # 0 = automatic: what it resolves to for this batch size
     if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the gather's kernels run beside a scoring kernel that always has 16 384 workgroups queued: give their stream the
+        # dispatcher's preference so that they take the free wavefront slots as soon as they are ready
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
