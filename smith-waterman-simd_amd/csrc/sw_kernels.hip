@@ -236,6 +236,10 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
         row_scores[i] = (int)lds_rows[wv][a];
     }
 
+    // from here on the wavefront only issues VALU work: let it win arbitration against wavefronts that are still in their
+    // (memory-bound) prologue (+0.4 %)
+    __builtin_amdgcn_s_setprio(2);
+
     // ---- anti-diagonal sweep, two steps per iteration ---------------------------------------------------
     // Three cell bodies, identical scores:
     //   FOLD            rows hold s + gap:  x = max3(left, up, dot4(row', onehot, diag)); h = x -sat gap; best tracks x
