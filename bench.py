@@ -197,6 +197,16 @@ def bench_banded(args, swmi, np, torch, local_rank):
     return 0
 
 
+def sg_sweep_kernel(P):
+    """Name of the sweep kernel launch_semiglobal picks for P alignments (same cost model as sg_kernels.hip)."""
+    if P < 6144:
+        return "sg_forward_kernel<8>"
+    w4, w2 = (P // 16 + 1023) // 1024, (P // 32 + 1023) // 1024
+    t4 = 17.3 if w4 <= 1 else 23.7 if w4 == 2 else 31.9 if w4 == 3 else 6.0 + 8.6 * w4
+    t2 = 39.9 if w2 <= 2 else 54.5 if w2 == 3 else 8.5 + 15.3 * w2
+    return "sg_forward_split_kernel<4, %d>" % min(max(w4, 1), 4) if t4 <= t2 else "sg_forward_split_kernel<2, %d>" % min(max(w2, 2), 4)
+
+
 def sg_traffic(P, kernel):
     """HBM bytes per launch of the sweep kernel from the committed PMC passes (65536 alignments), or None."""
     f = os.path.join(ROOT, "profiles", "r01_semiglobal_pmc.json")
@@ -257,7 +267,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     rounds, ops_cell = 32768, 9
     sweep_ops = P * rounds * 32 * ops_cell
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
-    sweep_kernel = "sg_forward_split_kernel<2>" if P >= 98304 else "sg_forward_split_kernel<4>" if P >= 6144 else "sg_forward_kernel"
+    sweep_kernel = sg_sweep_kernel(P)
     line["roofline"] = {
         "bound": "valu", "kernel": sweep_kernel,
         "kernel_ms": round(sweep_ms, 3), "achieved": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),

@@ -28,8 +28,7 @@ constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
 constexpr int kCodeStride = (kMaxRound + 7) & ~7;        // uint2 entries (8 B): 262208 B per alignment
 constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 65600 B per alignment
 // which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
-constexpr size_t kSplit4MinBatch = 6144;         // band over 4 lanes from here on, over 2 lanes from kSplit2MinBatch on
-constexpr size_t kSplit2MinBatch = 98304;
+constexpr size_t kSplit4MinBatch = 6144;         // band over 4 (later 2) lanes from here on
 constexpr size_t kLaneTracebackMinBatch = 3072;  // one lane per walk (+ expand kernel) from here on
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
@@ -62,7 +61,8 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 // per SIMD keep the issue port busy), so the body is branch-free and every cross-lane step is a DPP move or a v_readlane:
 // an LDS-crossbar shuffle (__shfl*, ds_bpermute_b32) costs more than all of a round's arithmetic.  The predecessor codes
 // fall out of three v_cmp masks combined on the scalar unit (the masks ARE the ballots).
-__global__ void __launch_bounds__(256)
+template <int W>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
                   uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
 {
@@ -205,8 +205,8 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
 //   * predecessor codes are collected as two C-bit words per round (vd != v, vu != v), shifted in as the sign of the
 //     difference; dropped cells carry no "live" bit: a path never enters a dropped cell (its value cannot equal a live
 //     cell's predecessor value), so the traceback never reads that bit.
-template <int G>
-__global__ void __launch_bounds__(64)
+template <int G, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
                         uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
 {
@@ -636,21 +636,50 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     // chip from a few thousand alignments), or the band split over 4 / 2 lanes (8 / 16 cells per lane: far fewer
     // instructions per alignment, need 16 / 32 alignments per wavefront)
     const char *force = getenv("SWMI_SG_SWEEP");
-    const int sweep = force ? atoi(force) : (n >= kSplit2MinBatch ? 2 : n >= kSplit4MinBatch ? 4 : 0);
-    if (sweep == 4 || sweep == 2) {
+    // SWMI_SG_SWEEP: 0 = band per half-wavefront; G or 10 * G + W = band over G lanes, scheduled for W wavefronts per SIMD
+    // The split kernels are compiled once per scheduling target W (amdgpu_waves_per_eu): hipcc orders the round for W
+    // resident wavefronts per SIMD, and the version whose W matches what the batch actually puts on a SIMD wins by 20-30 %
+    // (profiles/r01_sg_kernel_matrix.txt).
+    int sweep = 0;
+    if (force) {
+        sweep = atoi(force);
+        if (sweep == 4) sweep = 44;
+        if (sweep == 2) sweep = 24;
+    } else if (n >= kSplit4MinBatch) {
+        // wavefronts per SIMD the batch yields with 4 / 2 lanes per alignment (256 CUs x 4 SIMDs), and the sweep times
+        // measured for them (ms; both mappings take a fixed time per started wavefront-per-SIMD)
+        const int w4 = (int)((n / 16 + 1023) / 1024), w2 = (int)((n / 32 + 1023) / 1024);
+        const double t4 = w4 <= 1 ? 17.3 : w4 == 2 ? 23.7 : w4 == 3 ? 31.9 : 6.0 + 8.6 * w4;
+        const double t2 = w2 <= 2 ? 39.9 : w2 == 3 ? 54.5 : 8.5 + 15.3 * w2;
+        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 < 2 ? 2 : w2 > 4 ? 4 : w2);
+    }
+    if (sweep != 0 && sweep < 100) {
         const size_t words = n * 2 * (size_t)kStreamWords;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
                            (uint32_t)n, streams);
-        if (sweep == 4)
-            hipLaunchKernelGGL(sg_forward_split_kernel<4>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, streams,
-                               (uint32_t)n, codes, top, summary);
-        else
-            hipLaunchKernelGGL(sg_forward_split_kernel<2>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, stream, streams,
-                               (uint32_t)n, codes, top, summary);
+        const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32));
+#define SWMI_SG_LAUNCH(G, W, GRID) \
+    hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+        switch (sweep) {
+        case 41: SWMI_SG_LAUNCH(4, 1, grid4); break;
+        case 42: SWMI_SG_LAUNCH(4, 2, grid4); break;
+        case 43: SWMI_SG_LAUNCH(4, 3, grid4); break;
+        case 44: SWMI_SG_LAUNCH(4, 4, grid4); break;
+        case 21: SWMI_SG_LAUNCH(2, 1, grid2); break;
+        case 22: SWMI_SG_LAUNCH(2, 2, grid2); break;
+        case 23: SWMI_SG_LAUNCH(2, 3, grid2); break;
+        case 24: SWMI_SG_LAUNCH(2, 4, grid2); break;
+        default: return hipErrorInvalidValue;
+        }
+#undef SWMI_SG_LAUNCH
     } else {
         const unsigned waves = (unsigned)((n + 1) / 2);
-        hipLaunchKernelGGL(sg_forward_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes,
-                           top, summary);
+        const dim3 grid((waves + 3) / 4);
+        const int w = sweep > 100 ? sweep - 100 : 0;
+        if (w == 1) hipLaunchKernelGGL(sg_forward_kernel<1>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
+        else if (w == 2) hipLaunchKernelGGL(sg_forward_kernel<2>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
+        else if (w == 3) hipLaunchKernelGGL(sg_forward_kernel<3>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
+        else hipLaunchKernelGGL(sg_forward_kernel<8>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)

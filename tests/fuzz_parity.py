@@ -80,7 +80,7 @@ while time.time() < t_end:
     for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
         cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
-    os.environ["SWMI_SG_SWEEP"] = str((0, 4, 2)[sg_total // m % 3]); os.environ["SWMI_SG_TRACEBACK"] = str(sg_total // m % 2)
+    os.environ["SWMI_SG_SWEEP"] = str((0, 41, 42, 43, 44, 22, 23, 24)[sg_total // m % 8]); os.environ["SWMI_SG_TRACEBACK"] = str(sg_total // m % 2)
     scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
     with ThreadPoolExecutor(workers) as ex:
         ok = list(ex.map(check, [(a[k], b[k], int(scores[k]), tbs[k]) for k in range(m)]))

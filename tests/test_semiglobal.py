@@ -39,7 +39,7 @@ def sg_kernels(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1), (0, 1), (4, 0), (2, 0)])
+@pytest.mark.parametrize("sweep,traceback", [(0, 0), (4, 1), (2, 1), (0, 1), (4, 0), (2, 0), (41, 1), (42, 1), (43, 1), (22, 1), (23, 1)])
 def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep, traceback):
     sg_kernels(sweep, traceback)
     f = golden("f6_semiglobal")
