@@ -202,9 +202,9 @@ def sg_sweep_kernel(P):
     if P < 6144:
         return "sg_forward_kernel<8>"
     w4, w2 = (P // 16 + 1023) // 1024, (P // 32 + 1023) // 1024
-    t4 = 17.3 if w4 <= 1 else 23.7 if w4 == 2 else 31.9 if w4 == 3 else 6.0 + 8.6 * w4
-    t2 = 39.9 if w2 <= 2 else 54.5 if w2 == 3 else 8.5 + 15.3 * w2
-    return "sg_forward_split_kernel<4, %d>" % min(max(w4, 1), 4) if t4 <= t2 else "sg_forward_split_kernel<2, %d>" % min(max(w2, 2), 4)
+    t4 = 16.2 if w4 <= 1 else 23.5 if w4 == 2 else 31.7 if w4 == 3 else 5.7 + 8.57 * w4
+    t2 = 38.0 if w2 <= 2 else 6.6 + 15.45 * w2
+    return "sg_forward_split_kernel<4, %d>" % min(max(w4, 1), 4) if t4 <= t2 else "sg_forward_split_kernel<2, %d>" % (2 if w2 <= 2 else 3)
 
 
 def sg_traffic(P, kernel):

@@ -649,9 +649,9 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
         // wavefronts per SIMD the batch yields with 4 / 2 lanes per alignment (256 CUs x 4 SIMDs), and the sweep times
         // measured for them (ms; both mappings take a fixed time per started wavefront-per-SIMD)
         const int w4 = (int)((n / 16 + 1023) / 1024), w2 = (int)((n / 32 + 1023) / 1024);
-        const double t4 = w4 <= 1 ? 17.3 : w4 == 2 ? 23.7 : w4 == 3 ? 31.9 : 6.0 + 8.6 * w4;
-        const double t2 = w2 <= 2 ? 39.9 : w2 == 3 ? 54.5 : 8.5 + 15.3 * w2;
-        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 < 2 ? 2 : w2 > 4 ? 4 : w2);
+        const double t4 = w4 <= 1 ? 16.2 : w4 == 2 ? 23.5 : w4 == 3 ? 31.7 : 5.7 + 8.57 * w4;
+        const double t2 = w2 <= 2 ? 38.0 : 6.6 + 15.45 * w2;        // (W = 3 stays the fastest 2-lane build beyond 3 per SIMD)
+        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 <= 2 ? 2 : 3);
     }
     if (sweep != 0 && sweep < 100) {
         const size_t words = n * 2 * (size_t)kStreamWords;
