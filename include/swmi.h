@@ -148,7 +148,8 @@ SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, s
                                    int32_t *tracebacks, size_t cap, uint32_t *lengths);
 /* Same with every buffer resident in device memory; asynchronous on `stream`.  The library keeps a per-process
  * workspace of ~0.35 MB per alignment (2-bit predecessor codes, band rows, packed character streams, traceback
- * moves), grown on demand. */
+ * moves), grown on demand; because calls share it, two of them must not be in flight on different streams at once
+ * (calls on one stream serialise by themselves). */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
 /* Measurement helper (no reference counterpart): one swmi_semiglobal_xdrop_device call bracketed by HIP events on
