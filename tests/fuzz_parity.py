@@ -6,7 +6,8 @@ the reference's own TestSimdSmithWaterman idea (source.cpp:2943-2982: fresh rand
 
 Every round generates a fresh batch on the device (counter-based generator, new seed), scores it through the C ABI,
 copies the inputs back and scores them with oracle/liboracle.so on all host cores (OpenMP); any mismatch is dumped.
-A second phase does the same for the semi-global aligner against the reference's simd_mark4 (full tracebacks)."""
+A second phase does the same for the semi-global aligner against the reference's simd_mark4 (full tracebacks); a third
+one for the banded affine extension against the oracle's scalar Gotoh (random lengths, matrices, open / extend)."""
 import argparse, ctypes, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -18,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--batch", type=int, default=1 << 22)
 ap.add_argument("--sg-seconds", type=float, default=60)
+ap.add_argument("--ba-seconds", type=float, default=30)
 args = ap.parse_args()
 swmi.init(0)
 vp = ctypes.c_void_p
@@ -87,3 +89,26 @@ while time.time() < t_end:
     sg_total += m; sg_bad += m - sum(ok)
     print("... semi-global %d alignments, %d mismatches" % (sg_total, sg_bad), flush=True)
 print("semi-global fuzz vs %s: %d alignments (score + full traceback), %d mismatches" % ("reference simd_mark4" if ref else "oracle", sg_total, sg_bad), flush=True)
+
+# ---- banded affine extension vs oracle/sw_oracle.c (no reference counterpart: parity unpinned by the reference) ----
+orc.sw_oracle_banded_affine.restype = ctypes.c_int
+ba_total = ba_bad = 0
+t_end = time.time() + args.ba_seconds
+while time.time() < t_end:
+    length = int(rng.choice([64, 65, 100, 128, 200, 333, 512, 1000, 1024, 1500, 1792]))
+    m = int(rng.integers(1, 40))
+    a = rng.integers(0, 4, (m, length), dtype=np.uint8)
+    p = rng.random((m, 1)) * 0.4
+    b = np.where(rng.random((m, length)) < p, rng.integers(0, 4, (m, length), dtype=np.uint8), a).astype(np.uint8)
+    for k in range(0, m, 3):             # indels: offsets up to and beyond the band
+        cut = int(rng.integers(1, length)); sh = int(rng.integers(1, 80))
+        b[k, cut:] = np.roll(b[k], sh)[cut:]
+    kind = int(rng.integers(0, 3))       # any int8 matrix / match-mismatch with any gaps / the usual small gaps
+    sm = (rng.integers(-128, 128, 16) if kind == 0 else
+          np.where(np.eye(4, dtype=bool), rng.integers(0, 128), rng.integers(-128, 1)).reshape(16)).astype(np.int8)
+    go, ge = (int(rng.integers(0, 20)), int(rng.integers(0, 8))) if kind == 2 else (int(rng.integers(0, 128)), int(rng.integers(0, 128)))
+    got = swmi.score_banded_affine(a, b, sm, go, ge)
+    want = np.array([orc.sw_oracle_banded_affine(a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), length, sm.ctypes.data_as(vp), go, ge)
+                     for k in range(m)], np.int32)
+    ba_total += m; ba_bad += int((got != want).sum())
+print("banded affine fuzz vs oracle: %d alignments, %d mismatches (11 lengths 64..1792, random matrices, open/extend 0..127 either order)" % (ba_total, ba_bad), flush=True)
