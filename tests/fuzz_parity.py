@@ -45,7 +45,18 @@ while time.time() < t_end:
         m = torch.rand(n * 128, device="cuda") < 0.85
         half = (n // 2) * 128
         d2[:half] = torch.where(m[:half], d1[:half], d2[:half])
-    swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, gap, out.data_ptr(), st)
+    entry = rounds % 5                   # the sibling entry points share the kernel template: MODE 0 / 1 / 2
+    if entry == 3:                       # 2-bit packed inputs (source.cpp:1581), packed on the device
+        def pack(d):
+            v = d.view(n, 32, 4).to(torch.int32)
+            return (v[..., 0] | (v[..., 1] << 2) | (v[..., 2] << 4) | (v[..., 3] << 6)).to(torch.uint8).contiguous()
+        p1, p2 = pack(d1), pack(d2)
+        swmi.score_batch_device(p1.data_ptr(), p2.data_ptr(), n, sm, gap, out.data_ptr(), st, packed=True)
+    elif entry == 4:                     # every seq1 against ONE seq2 (source.cpp:1227)
+        d2.view(n, 128)[:] = d2[:128].clone()
+        swmi.score_one_vs_many_device(d1.data_ptr(), n, d2.data_ptr(), sm, gap, out.data_ptr(), st)
+    else:
+        swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), n, sm, gap, out.data_ptr(), st)
     torch.cuda.synchronize()
     a = d1.cpu().numpy(); b = d2.cpu().numpy(); got = out.cpu().numpy()
     want = np.zeros(n, np.int32)
@@ -57,7 +68,7 @@ while time.time() < t_end:
         print("MISMATCH seed %d first %d L %d gap %d sm %s: pair %d got %d want %d (%d bad)" % (seed, first, L, gap, sm.tolist(), i, got[i], want[i], bad), flush=True)
     if rounds % 10 == 0:
         print("... %d rounds, %.0f M pairs, %d mismatches" % (rounds, total / 1e6, mism), flush=True)
-print("SW128 fuzz: %d rounds, %d pairs, %d mismatches (all six schedules, folded and general cell, four parameter families)" % (rounds, total, mism), flush=True)
+print("SW128 fuzz: %d rounds, %d pairs, %d mismatches (all six schedules, folded and general cell, four parameter families, pairs / packed / one-vs-many entries)" % (rounds, total, mism), flush=True)
 
 # ---- semi-global aligner against the real reference (if present) or the oracle --------------------------------------
 ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
