@@ -46,7 +46,7 @@ extern "C" {
 
 #define SWMI_SEQ_LEN 128        /* std::array<uint8_t,128>, source.cpp:463-464 */
 #define SWMI_PACKED_LEN 32      /* std::array<uint8_t,32>,  source.cpp:1580     */
-#define SWMI_VERSION 100
+#define SWMI_VERSION 200
 
 enum swmi_status {
     SWMI_OK = 0,
@@ -60,14 +60,28 @@ enum swmi_status {
     SWMI_ERR_QUEUE_FULL = -8
 };
 
-/* ---- lifetime ----------------------------------------------------------------------- */
+/* ---- lifetime -----------------------------------------------------------------------
+ *
+ * The library keeps one CONTEXT per bound GPU (streams, staging buffers, workspaces).  Two ways to run:
+ *   one process per GPU   swmi_init(device): one context; what bench.py's ranks and every single-GPU caller use
+ *   one process, G GPUs   swmi_init_all(G) / swmi_init_devices(list): G contexts, index 0..G-1; the *_multi and
+ *                         swmi_sharded_* entry points below split a batch over them
+ * Every single-GPU entry point addresses the context the calling THREAD has selected with swmi_use_gpu(index)
+ * (default: index 0) and makes that context's device current (hipSetDevice) before it touches HIP -- the model of
+ * hipSetDevice itself.  The reference has no counterpart (a single-threaded CPU program, source.cpp:3275-3301). */
 
-/* Bind the calling process to one GPU (one process per GPU; device = ordinal as seen by
- * HIP, or -1 for "LOCAL_RANK env var if set, else 0").  Creates the library's streams and
- * workspace.  Idempotent for the same device.  The reference has no counterpart (it is a
- * single-threaded CPU program, source.cpp:3275-3301). */
+/* Bind the process to one GPU (device = ordinal as seen by HIP, or -1 for "LOCAL_RANK env var if set, else 0").
+ * Idempotent for the same device; another device needs swmi_shutdown() first. */
 SWMI_API int swmi_init(int device);
-SWMI_API int swmi_shutdown(void);
+/* Bind the first n_gpus visible devices (n_gpus <= 0: all of them).  Returns the number of contexts (> 0) or a negative
+ * swmi_status; every device must be gfx950.  Enables peer access between the bound devices where the platform allows. */
+SWMI_API int swmi_init_all(int n_gpus);
+/* Bind an explicit list.  A device may appear more than once -- two contexts on one GPU behave like two GPUs that share
+ * the hardware (how the multi-GPU path is rehearsed on a one-GPU box). */
+SWMI_API int swmi_init_devices(const int *devices, int n);
+SWMI_API int swmi_num_gpus(void);                 /* number of contexts (0 before init) */
+SWMI_API int swmi_use_gpu(int index);             /* select the context this thread's single-GPU calls address */
+SWMI_API int swmi_shutdown(void);                 /* must not race with other calls into the library */
 /* Text of the last error on the calling thread ("" if none). Never NULL. */
 SWMI_API const char *swmi_last_error(void);
 SWMI_API int swmi_version(void);
@@ -84,8 +98,11 @@ SWMI_API int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq
 
 /* The reference's 1M-call loop (source.cpp:3074-3082: `for 1,000,000: score = simd4(a,b,sm,gap)`)
  * as ONE call: pair k is the 128 bytes at seq1s + 128*k and seq2s + 128*k (the per-pair
- * layout of std::array<uint8_t,128>, concatenated).  Host buffers; the library stages them
- * through pinned memory in chunks, overlapping H2D copy, kernel and D2H copy.
+ * layout of std::array<uint8_t,128>, concatenated).  Host buffers (pageable or pinned); the library works in chunks of
+ * 1M pairs on two device buffer sets with a stream each, so that chunk k+1's H2D copy overlaps chunk k's kernel and D2H
+ * copy.  The copies are issued straight from the caller's memory (the HIP runtime stages pageable pages itself; an extra
+ * copy into library-owned pinned memory measured slower); batches of up to 64 pairs go through a
+ * pinned, device-visible buffer instead (no copy commands at all).  Thread-safe: calls on one context serialise.
  * scores[k] receives what SmithWaterman(seq1_k, seq2_k, score_matrix, gap) returns.
  * n may be 0.  Returns SWMI_OK or a negative swmi_status. */
 SWMI_API int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n,
@@ -119,6 +136,50 @@ SWMI_API int swmi_score_batch_packed_device(const void *d_seq1s_packed, const vo
                                             const int8_t score_matrix[16], int8_t gap_penalty,
                                             void *d_scores, void *stream);
 
+/* ---- multi-GPU: one batch over the G bound GPUs -----------------------------------------
+ * The reference's 1M-call loop (source.cpp:3074-3082) pointed at G GPUs.  Pairs are independent, so shard g of G is the
+ * contiguous range swmi_shard_bounds(n, g, G) (shards differ by at most one pair) and the only exchange step is the
+ * final gather of the int32 scores.  No input byte ever crosses GPUs. */
+SWMI_API int swmi_shard_bounds(size_t n, int shard, int n_shards, size_t *lo, size_t *hi);   /* needs no device */
+
+/* swmi_score_batch / swmi_score_batch_packed over every bound GPU: one host thread and one stream set per GPU, each
+ * copying its shard in, scoring it and copying its scores straight into the caller's slice scores[lo..hi). */
+SWMI_API int swmi_score_batch_multi(const uint8_t *seq1s, const uint8_t *seq2s, size_t n,
+                                    const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+SWMI_API int swmi_score_batch_packed_multi(const uint8_t *seq1s_packed, const uint8_t *seq2s_packed, size_t n,
+                                           const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+
+/* A batch whose shards stay RESIDENT on the GPUs (what a multi-GPU caller times): shard g of the inputs and of the scores
+ * lives in GPU g's HBM; swmi_sharded_score launches every GPU's kernel on that GPU's own stream and then runs the gather:
+ *   SWMI_GATHER_NONE   scores stay sharded (read them with swmi_sharded_scores_host)
+ *   SWMI_GATHER_ROOT   every GPU pushes its shard into the full int32[n] vector on GPU 0 (peer-to-peer DMA over xGMI)
+ *   SWMI_GATHER_ALL    every GPU ends up with the full vector: RCCL (librccl, loaded on first use; ncclAllGather for
+ *                      equal shards, grouped ncclBroadcast for ragged ones); peer copies when a GPU is bound twice
+ * All calls are asynchronous until swmi_sharded_wait. */
+typedef struct swmi_sharded_batch swmi_sharded_batch;
+enum swmi_gather { SWMI_GATHER_NONE = 0, SWMI_GATHER_ROOT = 1, SWMI_GATHER_ALL = 2 };
+SWMI_API int swmi_sharded_create(size_t n, int packed, swmi_sharded_batch **out);
+SWMI_API int swmi_sharded_destroy(swmi_sharded_batch *b);
+/* inputs: generated on each GPU from (seed, first_pair + global pair index), or copied from host arrays of n pairs */
+SWMI_API int swmi_sharded_generate(swmi_sharded_batch *b, uint64_t seed, uint64_t first_pair);
+SWMI_API int swmi_sharded_upload(swmi_sharded_batch *b, const uint8_t *seq1s, const uint8_t *seq2s);
+SWMI_API int swmi_sharded_score(swmi_sharded_batch *b, const int8_t score_matrix[16], int8_t gap_penalty, int gather);
+SWMI_API int swmi_sharded_wait(swmi_sharded_batch *b);
+/* scores[0..n) in pair order from the shards (synchronous, D2H from every GPU into its slice) */
+SWMI_API int swmi_sharded_scores_host(swmi_sharded_batch *b, int32_t *scores);
+/* device pointer of the gathered int32[n] vector on GPU `index` (valid after a score call with ROOT (index 0) / ALL) */
+SWMI_API int swmi_sharded_gathered_device(swmi_sharded_batch *b, int index, void **d_scores);
+/* the same vector copied to host memory (synchronous): what GPU `index` holds after the gather */
+SWMI_API int swmi_sharded_gathered_host(swmi_sharded_batch *b, int index, int32_t *scores);
+/* What SWMI_GATHER_ALL runs on for this batch: 2 = RCCL, 1 = peer copies (a GPU bound twice, librccl not loadable, or
+ * SWMI_GATHER_BACKEND=p2p), 0 = not decided yet (no SWMI_GATHER_ALL call so far). */
+SWMI_API int swmi_sharded_gather_backend(swmi_sharded_batch *b);
+/* Measurement: `iters` score calls back to back; kernel_ms[g] = average kernel time of GPU g (HIP events on its stream),
+ * gather_ms[g] = average time from the end of GPU g's kernel to the end of its part of the gather, *wall_ms = host wall
+ * time per call, everything drained.  kernel_ms / gather_ms have swmi_num_gpus() entries (NULL to skip). */
+SWMI_API int swmi_sharded_time(swmi_sharded_batch *b, const int8_t score_matrix[16], int8_t gap_penalty, int gather,
+                               int iters, float *kernel_ms, float *gather_ms, double *wall_ms);
+
 /* ---- extension: banded affine-gap scoring (BASELINE.json configs[4]; NO reference counterpart) -----------
  * The reference has linear gaps and no band on this path, so this entry point replaces
  * nothing in source.cpp; its semantics are defined by oracle/sw_oracle.c sw_oracle_banded_affine() and its
@@ -146,12 +207,18 @@ SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_
 #define SWMI_SG_MAX_TRACEBACK 32769
 SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
                                    int32_t *tracebacks, size_t cap, uint32_t *lengths);
-/* Same with every buffer resident in device memory; asynchronous on `stream`.  The library keeps a per-process
- * workspace of ~0.35 MB per alignment (2-bit predecessor codes, band rows, packed character streams, traceback
- * moves), grown on demand; because calls share it, two of them must not be in flight on different streams at once
- * (calls on one stream serialise by themselves). */
+/* Same with every buffer resident in device memory (every pointer 16-byte aligned: the kernels use 16-byte loads and
+ * 8-byte stores); asynchronous on `stream`.  The library keeps one workspace per (GPU, stream) of ~0.35 MB per alignment
+ * (2-bit predecessor codes, band rows, packed character streams, traceback moves), grown on demand and kept until
+ * swmi_semiglobal_release_workspaces() / swmi_shutdown(): calls on one stream serialise by themselves, calls on
+ * different streams use different workspaces and may be in flight together, from any threads. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
+/* Free the per-stream workspaces of the current GPU (synchronises the device first). */
+SWMI_API int swmi_semiglobal_release_workspaces(void);
+/* Names of the sweep and traceback kernels a call with n alignments runs on the current GPU (the mapping depends on the
+ * batch size and the device's CU count) -- so that a profiler-side tool asks instead of guessing. */
+SWMI_API int swmi_semiglobal_kernels_for_batch(size_t n, char *sweep, size_t sweep_len, char *traceback, size_t traceback_len);
 /* Measurement helper (no reference counterpart): one swmi_semiglobal_xdrop_device call bracketed by HIP events on
  * `stream`, synchronous; phase_ms[0] = the sweep kernel (source.cpp:1886-1949), phase_ms[1] = the traceback kernel
  * (source.cpp:1951-1975). */

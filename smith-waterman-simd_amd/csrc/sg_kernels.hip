@@ -15,6 +15,7 @@
 //     records its moves + a prefix-sum kernel that expands them (sg_walk_lane_kernel, sg_expand_kernel, large batches).
 #include "swmi_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -619,9 +620,54 @@ size_t semiglobal_workspace_bytes(size_t n)
     return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
 }
 
+namespace {
+// Which sweep a batch of n alignments runs: 0 / 100 + W = band per half-wavefront (one cell per lane: low latency, fills
+// the chip from a few thousand alignments); 10 * G + W = band split over G lanes (8 / 16 cells per lane: far fewer
+// instructions per alignment, 16 / 32 alignments per wavefront), compiled for W resident wavefronts per SIMD.
+// SWMI_SG_SWEEP forces one: 0, G or 10 * G + W.  The split kernels are compiled once per scheduling target W
+// (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per SIMD, and the version whose W matches what
+// the batch actually puts on a SIMD wins by 20-30 % (profiles/r01_sg_kernel_matrix.txt).
+int choose_sweep(size_t n, int compute_units)
+{
+    const char *force = getenv("SWMI_SG_SWEEP");
+    int sweep = 0;
+    if (force) {
+        sweep = atoi(force);
+        if (sweep == 4) sweep = 44;
+        if (sweep == 2) sweep = 24;
+    } else if (n >= kSplit4MinBatch) {
+        // wavefronts per SIMD the batch yields with 4 / 2 lanes per alignment on THIS device (4 SIMDs per CU; a partitioned
+        // gfx950 reports fewer CUs), and the sweep times measured for them on 256 CUs (ms; both mappings take a fixed time
+        // per started wavefront-per-SIMD, so the model carries over to other CU counts through w4 / w2)
+        const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
+        const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds);
+        const double t4 = w4 <= 1 ? 16.2 : w4 == 2 ? 23.5 : w4 == 3 ? 31.7 : 5.7 + 8.57 * w4;
+        const double t2 = w2 <= 2 ? 38.0 : 6.6 + 15.45 * w2;        // (W = 3 stays the fastest 2-lane build beyond 3 per SIMD)
+        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 <= 2 ? 2 : 3);
+    }
+    return sweep;
+}
+bool choose_lane_traceback(size_t n)
+{
+    const char *force_tb = getenv("SWMI_SG_TRACEBACK");
+    return force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;
+}
+}  // namespace
+
+void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len)
+{
+    const int sweep = choose_sweep(n, compute_units);
+    if (sweep_name && sweep_len) {
+        if (sweep != 0 && sweep < 100) snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep / 10, sweep % 10);
+        else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
+    }
+    if (tb_name && tb_len)
+        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
+}
+
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
-                             hipEvent_t between)
+                             hipEvent_t between, int compute_units)
 {
     if (n == 0) return hipSuccess;
     char *ws = static_cast<char *>(d_workspace);
@@ -632,27 +678,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     unsigned long long *moves = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
-    // three mappings of the sweep, same results: a band per half-wavefront (one cell per lane: low latency, fills the
-    // chip from a few thousand alignments), or the band split over 4 / 2 lanes (8 / 16 cells per lane: far fewer
-    // instructions per alignment, need 16 / 32 alignments per wavefront)
-    const char *force = getenv("SWMI_SG_SWEEP");
-    // SWMI_SG_SWEEP: 0 = band per half-wavefront; G or 10 * G + W = band over G lanes, scheduled for W wavefronts per SIMD
-    // The split kernels are compiled once per scheduling target W (amdgpu_waves_per_eu): hipcc orders the round for W
-    // resident wavefronts per SIMD, and the version whose W matches what the batch actually puts on a SIMD wins by 20-30 %
-    // (profiles/r01_sg_kernel_matrix.txt).
-    int sweep = 0;
-    if (force) {
-        sweep = atoi(force);
-        if (sweep == 4) sweep = 44;
-        if (sweep == 2) sweep = 24;
-    } else if (n >= kSplit4MinBatch) {
-        // wavefronts per SIMD the batch yields with 4 / 2 lanes per alignment (256 CUs x 4 SIMDs), and the sweep times
-        // measured for them (ms; both mappings take a fixed time per started wavefront-per-SIMD)
-        const int w4 = (int)((n / 16 + 1023) / 1024), w2 = (int)((n / 32 + 1023) / 1024);
-        const double t4 = w4 <= 1 ? 16.2 : w4 == 2 ? 23.5 : w4 == 3 ? 31.7 : 5.7 + 8.57 * w4;
-        const double t2 = w2 <= 2 ? 38.0 : 6.6 + 15.45 * w2;        // (W = 3 stays the fastest 2-lane build beyond 3 per SIMD)
-        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 <= 2 ? 2 : 3);
-    }
+    const int sweep = choose_sweep(n, compute_units);
     if (sweep != 0 && sweep < 100) {
         const size_t words = n * 2 * (size_t)kStreamWords;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
@@ -684,8 +710,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
-    const char *force_tb = getenv("SWMI_SG_TRACEBACK");
-    const bool lane_tb = force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;
+    const bool lane_tb = choose_lane_traceback(n);
     if (lane_tb) {
         hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
                            summary, moves, d_scores, d_lengths);

@@ -4,23 +4,26 @@
 // pipelining for host-resident batches, the deferred queue behind the per-pair signature, and
 // hipEvent timing.  There is deliberately no CPU implementation of the scoring path in this
 // library: without a usable gfx950 device every scoring entry point returns an error.
-#include "../../include/swmi.h"
-#include "swmi_internal.h"
+#include "swmi_host.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
-#include <vector>
+
+namespace swmi {
+namespace host {
 
 namespace {
-
-using swmi::LaunchConfig;
-using swmi::SmRows;
-
 thread_local char t_error[512] = "";
+thread_local int t_gpu = 0;                        // context index this thread addresses (swmi_use_gpu)
+std::vector<std::unique_ptr<Context>> g_ctxs;      // written only under g_init_mu, by swmi_init* / swmi_shutdown
+std::mutex g_init_mu;
+// Schedule setting, process-wide: lanes in the low half, flags in the high half, ONE atomic so that a launch that races
+// with swmi_set_schedule sees either the old pair or the new one, never a mix.
+std::atomic<uint64_t> g_schedule{0};
+}  // namespace
 
 int fail(int code, const char *fmt, ...)
 {
@@ -31,60 +34,27 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(SWMI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+std::mutex &init_mutex() { return g_init_mu; }
+int num_contexts() { return (int)g_ctxs.size(); }
+Context *context_at(int index) { return index >= 0 && index < (int)g_ctxs.size() ? g_ctxs[index].get() : nullptr; }
 
-constexpr size_t kSeq = SWMI_SEQ_LEN;
-constexpr size_t kChunkPairs = size_t(1) << 20;      // host-batch pipeline granule: 1M pairs = 128 MiB per input array
-constexpr size_t kMaxLaunchPairs = size_t(1) << 30;  // pairs per kernel launch (kernel indexes pairs with uint32)
-constexpr int kSlots = 2;
-constexpr size_t kPinPairs = 64;        // host batches up to this size go through the pinned staging buffer
-
-struct Slot {
-    hipStream_t stream = nullptr;
-    uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
-    int32_t *d_scores = nullptr;
-    size_t capacity = 0;   // pairs
-};
-
-struct Context {
-    bool ready = false;
-    int device = -1;
-    hipDeviceProp_t prop{};
-    hipStream_t stream = nullptr;       // library-owned stream (host-side helpers)
-    Slot slots[kSlots];
-    int lanes = 0;                      // 0 = automatic: by batch size (auto_lanes)
-    unsigned flags = 0;
-    void *sg_workspace = nullptr;       // semi-global aligner workspace (device), grown on demand
-    size_t sg_workspace_bytes = 0;
-    unsigned extra_lds = 0;             // SWMI_EXTRA_LDS: occupancy sweep knob (BASELINE config 3)
-    // pinned, device-visible staging for tiny host batches (the per-pair call): the kernel reads the pairs from host
-    // memory and writes the scores back there, so a call is one launch + one synchronisation, no copies
-    // device buffers of the host-buffer semi-global entry (two chunks in flight), kept between calls and grown on demand
-    struct SgSet {
-        uint8_t *d1 = nullptr, *d2 = nullptr;
-        void *ws = nullptr;
-        int32_t *d_scores = nullptr, *d_tb = nullptr;
-        uint32_t *d_len = nullptr;
-        size_t alignments = 0, tb_entries = 0;      // capacity
-        size_t off = 0, m = 0;                      // chunk in flight
-    } sg_sets[2];
-    uint8_t *pin = nullptr;             // [kPinPairs * 128] seq1s, [kPinPairs * 128] seq2s, [kPinPairs] int32 scores
-    void *pin_dev = nullptr;            // the same memory as the device sees it
-    std::mutex mu;                      // serialises use of the slots
-};
-
-Context g_ctx;
-std::mutex g_init_mu;
-
-int check_ready()
+Context *current()
 {
-    if (!g_ctx.ready) return fail(SWMI_ERR_NOT_INITIALIZED, "swmi_init() has not been called (or failed)");
-    return SWMI_OK;
+    if (g_ctxs.empty()) {
+        fail(SWMI_ERR_NOT_INITIALIZED, "swmi_init() has not been called (or failed)");
+        return nullptr;
+    }
+    Context *ctx = context_at(t_gpu);
+    if (!ctx) {
+        fail(SWMI_ERR_INVALID_ARGUMENT, "this thread selected GPU index %d but only %d are bound", t_gpu, (int)g_ctxs.size());
+        return nullptr;
+    }
+    const hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) {
+        fail(SWMI_ERR_HIP, "hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(e));
+        return nullptr;
+    }
+    return ctx;
 }
 
 int check_params(const int8_t *sm, int gap)
@@ -106,6 +76,7 @@ SmRows pack_rows(const int8_t *sm, int add)
     return rows;
 }
 
+namespace {
 // Lanes per alignment when the caller has not fixed a schedule: L = 4 (32 rows per lane) issues the fewest instructions
 // per cell and wins once the batch fills the chip; a small batch wants many lanes per alignment instead -- a single pair
 // takes 6 us with L = 64 and 42 us with L = 4 (tools/small_batch_schedule.py, profiles/r01_small_batch_schedule.txt).
@@ -113,16 +84,25 @@ int auto_lanes(size_t n)
 {
     return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 20480 ? 16 : 4;
 }
+int resolve_lanes(uint64_t schedule, size_t n)
+{
+    const int lanes = int(schedule & 0xffffffffu);
+    const unsigned flags = unsigned(schedule >> 32);
+    return lanes ? lanes : (flags & swmi::kUseLut) ? 4 : auto_lanes(n);
+}
+}  // namespace
 
 // Choose the schedule and the cell body: the gap-folded recurrence needs every sm + gap to fit int8.
-LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows, size_t n)
+LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *rows, size_t n)
 {
+    const uint64_t schedule = g_schedule.load(std::memory_order_relaxed);     // one snapshot per launch
+    const unsigned flags = unsigned(schedule >> 32);
     LaunchConfig cfg;
-    cfg.lanes_per_alignment = g_ctx.lanes ? g_ctx.lanes : (g_ctx.flags & swmi::kUseLut) ? 4 : auto_lanes(n);
-    cfg.use_i16 = (g_ctx.flags & swmi::kUseI16) != 0;
-    cfg.use_lut = (g_ctx.flags & swmi::kUseLut) != 0;
-    cfg.extra_lds_bytes = g_ctx.extra_lds;
-    bool fold = !(g_ctx.flags & swmi::kNoGapFold);
+    cfg.lanes_per_alignment = resolve_lanes(schedule, n);
+    cfg.use_i16 = (flags & swmi::kUseI16) != 0;
+    cfg.use_lut = (flags & swmi::kUseLut) != 0;
+    cfg.extra_lds_bytes = ctx.extra_lds;
+    bool fold = !(flags & swmi::kNoGapFold);
     for (int k = 0; k < 16 && fold; ++k) {
         const int v = int(sm[k]) + gap;
         if (v < -128 || v > 127) fold = false;
@@ -132,6 +112,7 @@ LaunchConfig make_config(const int8_t *sm, int gap, SmRows *rows, size_t n)
     return cfg;
 }
 
+namespace {
 int ensure_slot(Slot &s, size_t pairs)
 {
     if (s.capacity >= pairs) return SWMI_OK;
@@ -139,67 +120,80 @@ int ensure_slot(Slot &s, size_t pairs)
     if (s.d_seq2) { (void)hipFree(s.d_seq2); s.d_seq2 = nullptr; }
     if (s.d_scores) { (void)hipFree(s.d_scores); s.d_scores = nullptr; }
     s.capacity = 0;
-    HIP_TRY(hipMalloc(&s.d_seq1, pairs * kSeq));
-    HIP_TRY(hipMalloc(&s.d_seq2, pairs * kSeq));
-    HIP_TRY(hipMalloc(&s.d_scores, pairs * sizeof(int32_t)));
+    SWMI_HIP_TRY(hipMalloc(&s.d_seq1, pairs * kSeq));
+    SWMI_HIP_TRY(hipMalloc(&s.d_seq2, pairs * kSeq));
+    SWMI_HIP_TRY(hipMalloc(&s.d_scores, pairs * sizeof(int32_t)));
     s.capacity = pairs;
-    return SWMI_OK;
-}
-
-int launch_device(const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out, hipStream_t st,
-                  bool packed)
-{
-    SmRows rows;
-    const LaunchConfig cfg = make_config(sm, gap, &rows, n);
-    const size_t stride = packed ? SWMI_PACKED_LEN : kSeq;
-    for (size_t off = 0; off < n; off += kMaxLaunchPairs) {
-        const size_t m = n - off < kMaxLaunchPairs ? n - off : kMaxLaunchPairs;
-        HIP_TRY(swmi::launch_score(cfg, static_cast<const uint8_t *>(d1) + off * stride,
-                                   static_cast<const uint8_t *>(d2) + off * stride,
-                                   static_cast<int32_t *>(d_out) + off, m, rows, gap, packed, st));
-    }
-    return SWMI_OK;
-}
-
-// Host-resident batch: two slots, each with its own stream; chunk k+1's H2D copy overlaps chunk k's kernel.
-int score_host_batch(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
-                     bool packed, bool one_vs_many)
-{
-    std::lock_guard<std::mutex> lock(g_ctx.mu);
-    const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
-    const size_t chunk = n < kChunkPairs ? n : kChunkPairs;
-    SmRows rows;
-    const LaunchConfig cfg = make_config(sm, gap, &rows, chunk);
-    for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
-        const int rc = ensure_slot(g_ctx.slots[k], chunk);
-        if (rc != SWMI_OK) return rc;
-    }
-    if (one_vs_many)   // the single seq2 goes to the head of slot 0's seq2 buffer... of every slot in use
-        for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k)
-            HIP_TRY(hipMemcpyAsync(g_ctx.slots[k].d_seq2, s2, kSeq, hipMemcpyHostToDevice, g_ctx.slots[k].stream));
-    size_t idx = 0;
-    for (size_t off = 0; off < n; off += chunk, ++idx) {
-        Slot &s = g_ctx.slots[idx % kSlots];
-        const size_t m = n - off < chunk ? n - off : chunk;
-        HIP_TRY(hipMemcpyAsync(s.d_seq1, s1 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream));
-        if (!one_vs_many)
-            HIP_TRY(hipMemcpyAsync(s.d_seq2, s2 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream));
-        if (one_vs_many)
-            HIP_TRY(swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, s.stream));
-        else
-            HIP_TRY(swmi::launch_score(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, packed, s.stream));
-        HIP_TRY(hipMemcpyAsync(out + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-    }
-    for (int k = 0; k < kSlots; ++k)
-        if (g_ctx.slots[k].stream) HIP_TRY(hipStreamSynchronize(g_ctx.slots[k].stream));
     return SWMI_OK;
 }
 
 }  // namespace
 
+int launch_device(Context &ctx, const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out,
+                  hipStream_t st, bool packed)
+{
+    SmRows rows;
+    const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, n);
+    const size_t stride = packed ? SWMI_PACKED_LEN : kSeq;
+    for (size_t off = 0; off < n; off += kMaxLaunchPairs) {
+        const size_t m = n - off < kMaxLaunchPairs ? n - off : kMaxLaunchPairs;
+        SWMI_HIP_TRY(swmi::launch_score(cfg, static_cast<const uint8_t *>(d1) + off * stride,
+                                        static_cast<const uint8_t *>(d2) + off * stride,
+                                        static_cast<int32_t *>(d_out) + off, m, rows, gap, packed, st));
+    }
+    return SWMI_OK;
+}
+
+// Host-resident batch: two slots, each with its own stream; chunk k+1's H2D copy overlaps chunk k's kernel.
+int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
+                     bool packed, bool one_vs_many)
+{
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
+    const size_t chunk = n < kChunkPairs ? n : kChunkPairs;
+    SmRows rows;
+    const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, chunk);
+    for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
+        const int rc = ensure_slot(ctx.slots[k], chunk);
+        if (rc != SWMI_OK) return rc;
+    }
+    hipError_t e = hipSuccess;
+    if (one_vs_many)   // the single seq2 goes to the head of the seq2 buffer of every slot in use
+        for (int k = 0; k < kSlots && size_t(k) * chunk < n && e == hipSuccess; ++k)
+            e = hipMemcpyAsync(ctx.slots[k].d_seq2, s2, kSeq, hipMemcpyHostToDevice, ctx.slots[k].stream);
+    size_t idx = 0;
+    for (size_t off = 0; off < n && e == hipSuccess; off += chunk, ++idx) {
+        Slot &s = ctx.slots[idx % kSlots];
+        const size_t m = n - off < chunk ? n - off : chunk;
+        e = hipMemcpyAsync(s.d_seq1, s1 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess && !one_vs_many)
+            e = hipMemcpyAsync(s.d_seq2, s2 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess)
+            e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, s.stream)
+                            : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, packed, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+    }
+    for (int k = 0; k < kSlots; ++k)
+        if (ctx.slots[k].stream) {
+            const hipError_t es = hipStreamSynchronize(ctx.slots[k].stream);      // on failure too: see drain_slots
+            if (e == hipSuccess) e = es;
+        }
+    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "host batch on GPU %d failed: %s", ctx.device, hipGetErrorString(e));
+    return SWMI_OK;
+}
+
+}  // namespace host
+}  // namespace swmi
+
+using namespace swmi::host;
+using swmi::LaunchConfig;
+using swmi::SmRows;
+#define HIP_TRY SWMI_HIP_TRY
+
 // ---- deferred queue ------------------------------------------------------------------------------
 
 struct swmi_queue {
+    Context *ctx = nullptr;             // the GPU the queue was created on
     size_t max_pairs = 0, count = 0, shipped = 0;
     size_t block = 1 << 16;             // pairs per asynchronous shipment
     int8_t sm[16];
@@ -215,14 +209,99 @@ namespace {
 int queue_ship(swmi_queue *q, size_t upto)
 {
     if (upto <= q->shipped) return SWMI_OK;
+    HIP_TRY(hipSetDevice(q->ctx->device));
     const size_t off = q->shipped, m = upto - q->shipped;
     HIP_TRY(hipMemcpyAsync(q->d_seq1 + off * kSeq, q->h_seq1 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
     HIP_TRY(hipMemcpyAsync(q->d_seq2 + off * kSeq, q->h_seq2 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
-    const int rc = launch_device(q->d_seq1 + off * kSeq, q->d_seq2 + off * kSeq, m, q->sm, q->gap, q->d_scores + off,
+    const int rc = launch_device(*q->ctx, q->d_seq1 + off * kSeq, q->d_seq2 + off * kSeq, m, q->sm, q->gap, q->d_scores + off,
                                  q->stream, false);
     if (rc != SWMI_OK) return rc;
     HIP_TRY(hipMemcpyAsync(q->h_scores + off, q->d_scores + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, q->stream));
     q->shipped = upto;
+    return SWMI_OK;
+}
+
+void destroy_context(Context &c)
+{
+    (void)hipSetDevice(c.device);
+    (void)hipDeviceSynchronize();
+    for (auto &s : c.slots) {
+        if (s.d_seq1) (void)hipFree(s.d_seq1);
+        if (s.d_seq2) (void)hipFree(s.d_seq2);
+        if (s.d_scores) (void)hipFree(s.d_scores);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s = Slot{};
+    }
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    for (auto &w : c.sg_workspaces)
+        if (w.second.ptr) (void)hipFree(w.second.ptr);
+    c.sg_workspaces.clear();
+    for (auto &g : c.sg_sets) {
+        (void)hipFree(g.d1); (void)hipFree(g.d2); (void)hipFree(g.ws); (void)hipFree(g.d_scores); (void)hipFree(g.d_len); (void)hipFree(g.d_tb);
+        g = SgSet{};
+    }
+    if (c.pin) (void)hipHostFree(c.pin);
+    c.pin = nullptr;
+    c.pin_dev = nullptr;
+}
+
+int create_context(Context &c, int index, int device)
+{
+    c.index = index;
+    c.device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDeviceProperties(&c.prop, device));
+    if (strncmp(c.prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SWMI_ERR_UNSUPPORTED_ARCH, "device %d is %s; libswmi carries gfx950 (MI355X) code objects only", device,
+                    c.prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto &s : c.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.pin), kPinPairs * (2 * kSeq + sizeof(int32_t)), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(&c.pin_dev, c.pin, 0));
+    const char *env_x = getenv("SWMI_EXTRA_LDS");
+    c.extra_lds = env_x ? (unsigned)atoi(env_x) : 0;
+    return SWMI_OK;
+}
+
+// Bind the listed devices (under g_init_mu).  All or nothing.
+int init_list(const int *devices, int n)
+{
+    std::vector<std::unique_ptr<Context>> fresh;
+    for (int k = 0; k < n; ++k) {
+        fresh.emplace_back(new Context);
+        const int rc = create_context(*fresh.back(), k, devices[k]);
+        if (rc != SWMI_OK) {
+            for (auto &c : fresh) destroy_context(*c);
+            return rc;
+        }
+    }
+    // peer access between distinct bound devices: lets the score gather go GPU to GPU over xGMI (swmi_multi.cpp); where the
+    // platform refuses, hipMemcpyPeerAsync still works (staged by the runtime), so failures are not errors
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            if (devices[a] != devices[b]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[a]);
+                    (void)hipDeviceEnablePeerAccess(devices[b], 0);
+                    (void)hipGetLastError();            // "already enabled" is fine
+                }
+            }
+    (void)hipSetDevice(devices[0]);
+    g_ctxs = std::move(fresh);
+    const char *env_l = getenv("SWMI_LANES");
+    if (env_l && swmi::schedule_supported(atoi(env_l))) g_schedule.store(uint64_t(atoi(env_l)));
+    return SWMI_OK;
+}
+
+int device_count_or_fail(int *count)
+{
+    *count = 0;
+    const hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess || *count <= 0)
+        return fail(SWMI_ERR_NO_DEVICE, "no HIP device available (%s); libswmi has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     return SWMI_OK;
 }
 }  // namespace
@@ -238,65 +317,74 @@ int swmi_init(int device)
     std::lock_guard<std::mutex> lock(g_init_mu);
     t_error[0] = 0;
     int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(SWMI_ERR_NO_DEVICE, "no HIP device available (%s); libswmi has no CPU fallback",
-                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    int rc = device_count_or_fail(&count);
+    if (rc != SWMI_OK) return rc;
     if (device < 0) {
         const char *lr = getenv("LOCAL_RANK");
         device = lr ? atoi(lr) % count : 0;
     }
     if (device >= count) return fail(SWMI_ERR_INVALID_ARGUMENT, "device %d out of range (count %d)", device, count);
-    if (g_ctx.ready) {
-        if (g_ctx.device == device) return SWMI_OK;
-        return fail(SWMI_ERR_INVALID_ARGUMENT, "already initialised on device %d (one process per GPU); call swmi_shutdown() first",
-                    g_ctx.device);
+    if (!g_ctxs.empty()) {
+        if (g_ctxs.size() == 1 && g_ctxs[0]->device == device) return SWMI_OK;
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "already initialised (%zu GPU(s), first is device %d); call swmi_shutdown() first",
+                    g_ctxs.size(), g_ctxs[0]->device);
     }
-    HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipGetDeviceProperties(&g_ctx.prop, device));
-    if (strncmp(g_ctx.prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(SWMI_ERR_UNSUPPORTED_ARCH, "device %d is %s; libswmi carries gfx950 (MI355X) code objects only", device,
-                    g_ctx.prop.gcnArchName);
-    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-    for (auto &s : g_ctx.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    g_ctx.device = device;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_ctx.pin), kPinPairs * (2 * kSeq + sizeof(int32_t)), hipHostMallocMapped));
-    HIP_TRY(hipHostGetDevicePointer(&g_ctx.pin_dev, g_ctx.pin, 0));
-    const char *env_x = getenv("SWMI_EXTRA_LDS");
-    g_ctx.extra_lds = env_x ? (unsigned)atoi(env_x) : 0;
-    const char *env_l = getenv("SWMI_LANES");
-    if (env_l && swmi::schedule_supported(atoi(env_l))) g_ctx.lanes = atoi(env_l);
-    g_ctx.ready = true;
+    return init_list(&device, 1);
+}
+
+int swmi_init_devices(const int *devices, int n)
+{
+    std::lock_guard<std::mutex> lock(g_init_mu);
+    t_error[0] = 0;
+    if (!devices || n <= 0 || n > 64) return fail(SWMI_ERR_INVALID_ARGUMENT, "device list is NULL or its length %d is outside [1, 64]", n);
+    int count = 0;
+    int rc = device_count_or_fail(&count);
+    if (rc != SWMI_OK) return rc;
+    for (int k = 0; k < n; ++k)
+        if (devices[k] < 0 || devices[k] >= count)
+            return fail(SWMI_ERR_INVALID_ARGUMENT, "device %d (entry %d) out of range (count %d)", devices[k], k, count);
+    if (!g_ctxs.empty()) {
+        bool same = (int)g_ctxs.size() == n;
+        for (int k = 0; same && k < n; ++k) same = g_ctxs[k]->device == devices[k];
+        if (same) return n;
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "already initialised with a different device list; call swmi_shutdown() first");
+    }
+    rc = init_list(devices, n);
+    return rc == SWMI_OK ? n : rc;
+}
+
+int swmi_init_all(int n_gpus)
+{
+    int count = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_init_mu);
+        t_error[0] = 0;
+        const int rc = device_count_or_fail(&count);
+        if (rc != SWMI_OK) return rc;
+    }
+    if (n_gpus <= 0) n_gpus = count;
+    if (n_gpus > count) return fail(SWMI_ERR_INVALID_ARGUMENT, "%d GPUs requested, %d visible", n_gpus, count);
+    std::vector<int> devices(n_gpus);
+    for (int k = 0; k < n_gpus; ++k) devices[k] = k;
+    return swmi_init_devices(devices.data(), n_gpus);
+}
+
+int swmi_num_gpus(void) { return num_contexts(); }
+
+int swmi_use_gpu(int index)
+{
+    if (index < 0 || (!g_ctxs.empty() && index >= (int)g_ctxs.size()))
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "GPU index %d out of range (%d bound)", index, (int)g_ctxs.size());
+    t_gpu = index;
     return SWMI_OK;
 }
 
 int swmi_shutdown(void)
 {
     std::lock_guard<std::mutex> lock(g_init_mu);
-    if (!g_ctx.ready) return SWMI_OK;
-    (void)hipSetDevice(g_ctx.device);
-    (void)hipDeviceSynchronize();
-    for (auto &s : g_ctx.slots) {
-        if (s.d_seq1) (void)hipFree(s.d_seq1);
-        if (s.d_seq2) (void)hipFree(s.d_seq2);
-        if (s.d_scores) (void)hipFree(s.d_scores);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
-        s = Slot{};
-    }
-    if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
-    g_ctx.stream = nullptr;
-    if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
-    g_ctx.sg_workspace = nullptr;
-    g_ctx.sg_workspace_bytes = 0;
-    for (auto &g : g_ctx.sg_sets) {
-        (void)hipFree(g.d1); (void)hipFree(g.d2); (void)hipFree(g.ws); (void)hipFree(g.d_scores); (void)hipFree(g.d_len); (void)hipFree(g.d_tb);
-        g = Context::SgSet{};
-    }
-    if (g_ctx.pin) (void)hipHostFree(g_ctx.pin);
-    g_ctx.pin = nullptr;
-    g_ctx.pin_dev = nullptr;
-    g_ctx.ready = false;
-    g_ctx.device = -1;
+    for (auto &c : g_ctxs) destroy_context(*c);
+    g_ctxs.clear();
+    t_gpu = 0;
     return SWMI_OK;
 }
 
@@ -305,36 +393,33 @@ int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
     if (lanes_per_alignment != 0 && !swmi::schedule_supported(lanes_per_alignment))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
     if (flags & ~7u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
-    g_ctx.lanes = lanes_per_alignment;
-    g_ctx.flags = flags;
+    g_schedule.store(uint64_t(uint32_t(lanes_per_alignment)) | (uint64_t(flags) << 32));
     return SWMI_OK;
 }
 
 int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags)
 {
-    if (lanes_per_alignment) *lanes_per_alignment = g_ctx.lanes;      // 0 = automatic
-    if (flags) *flags = g_ctx.flags;
+    const uint64_t s = g_schedule.load();
+    if (lanes_per_alignment) *lanes_per_alignment = int(s & 0xffffffffu);      // 0 = automatic
+    if (flags) *flags = unsigned(s >> 32);
     return SWMI_OK;
 }
 
-int swmi_schedule_for_batch(size_t n)
-{
-    return g_ctx.lanes ? g_ctx.lanes : (g_ctx.flags & swmi::kUseLut) ? 4 : auto_lanes(n);
-}
+int swmi_schedule_for_batch(size_t n) { return resolve_lanes(g_schedule.load(), n); }
 
 int swmi_get_device_info(swmi_device_info *info)
 {
     if (!info) return fail(SWMI_ERR_INVALID_ARGUMENT, "info is NULL");
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
     memset(info, 0, sizeof *info);
-    info->device = g_ctx.device;
-    info->compute_units = g_ctx.prop.multiProcessorCount;
-    info->clock_khz = g_ctx.prop.clockRate;
-    info->wavefront_size = g_ctx.prop.warpSize;
-    info->hbm_bytes = g_ctx.prop.totalGlobalMem;
-    snprintf(info->arch, sizeof info->arch, "%s", g_ctx.prop.gcnArchName);
-    snprintf(info->name, sizeof info->name, "%s", g_ctx.prop.name);
+    info->device = ctx->device;
+    info->compute_units = ctx->prop.multiProcessorCount;
+    info->clock_khz = ctx->prop.clockRate;
+    info->wavefront_size = ctx->prop.warpSize;
+    info->hbm_bytes = ctx->prop.totalGlobalMem;
+    snprintf(info->arch, sizeof info->arch, "%s", ctx->prop.gcnArchName);
+    snprintf(info->name, sizeof info->name, "%s", ctx->prop.name);
     return SWMI_OK;
 }
 
@@ -345,23 +430,23 @@ int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, const
     if (rc != SWMI_OK) return rc;
     if (n == 0) return SWMI_OK;
     if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
     if (n <= kPinPairs) {               // the per-pair call and its small relatives: no copies, one launch, one wait
-        std::lock_guard<std::mutex> lock(g_ctx.mu);
-        uint8_t *h1 = g_ctx.pin, *h2 = g_ctx.pin + kPinPairs * kSeq;
-        int32_t *hs = reinterpret_cast<int32_t *>(g_ctx.pin + 2 * kPinPairs * kSeq);
-        uint8_t *dev = static_cast<uint8_t *>(g_ctx.pin_dev);
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        uint8_t *h1 = ctx->pin, *h2 = ctx->pin + kPinPairs * kSeq;
+        int32_t *hs = reinterpret_cast<int32_t *>(ctx->pin + 2 * kPinPairs * kSeq);
+        uint8_t *dev = static_cast<uint8_t *>(ctx->pin_dev);
         memcpy(h1, seq1s, n * kSeq);
         memcpy(h2, seq2s, n * kSeq);
-        rc = launch_device(dev, dev + kPinPairs * kSeq, n, score_matrix, gap_penalty, dev + 2 * kPinPairs * kSeq, g_ctx.stream, false);
+        rc = launch_device(*ctx, dev, dev + kPinPairs * kSeq, n, score_matrix, gap_penalty, dev + 2 * kPinPairs * kSeq, ctx->stream, false);
+        const hipError_t es = hipStreamSynchronize(ctx->stream);
         if (rc != SWMI_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        if (es != hipSuccess) return fail(SWMI_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
         memcpy(scores, hs, n * sizeof(int32_t));
         return SWMI_OK;
     }
-    return score_host_batch(seq1s, seq2s, n, score_matrix, gap_penalty, scores, false, false);
+    return score_host_batch(*ctx, seq1s, seq2s, n, score_matrix, gap_penalty, scores, false, false);
 }
 
 int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq2[SWMI_SEQ_LEN], const int8_t score_matrix[16],
@@ -379,10 +464,9 @@ int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t se
     if (rc != SWMI_OK) return rc;
     if (n_seq1 == 0) return SWMI_OK;
     if (!seq1s || !seq2 || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seq1 = %zu", n_seq1);
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    HIP_TRY(hipSetDevice(g_ctx.device));
-    return score_host_batch(seq1s, seq2, n_seq1, score_matrix, gap_penalty, scores, false, true);
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    return score_host_batch(*ctx, seq1s, seq2, n_seq1, score_matrix, gap_penalty, scores, false, true);
 }
 
 int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void *d_seq2, const int8_t score_matrix[16],
@@ -394,10 +478,10 @@ int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void
     if (!d_seq1s || !d_seq2 || !d_scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n_seq1 = %zu", n_seq1);
     if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2) | reinterpret_cast<uintptr_t>(d_scores)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
     SmRows rows;
-    const LaunchConfig cfg = make_config(score_matrix, gap_penalty, &rows, n_seq1);
+    const LaunchConfig cfg = make_config(*ctx, score_matrix, gap_penalty, &rows, n_seq1);
     for (size_t off = 0; off < n_seq1; off += kMaxLaunchPairs) {
         const size_t m = n_seq1 - off < kMaxLaunchPairs ? n_seq1 - off : kMaxLaunchPairs;
         HIP_TRY(swmi::launch_score_one_vs_many(cfg, static_cast<const uint8_t *>(d_seq1s) + off * kSeq,
@@ -414,10 +498,9 @@ int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_pa
     if (rc != SWMI_OK) return rc;
     if (n == 0) return SWMI_OK;
     if (!seq1s_packed || !seq2s_packed || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    HIP_TRY(hipSetDevice(g_ctx.device));
-    return score_host_batch(seq1s_packed, seq2s_packed, n, score_matrix, gap_penalty, scores, true, false);
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    return score_host_batch(*ctx, seq1s_packed, seq2s_packed, n, score_matrix, gap_penalty, scores, true, false);
 }
 
 static int device_entry(const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out, void *stream,
@@ -429,10 +512,10 @@ static int device_entry(const void *d1, const void *d2, size_t n, const int8_t *
     if (!d1 || !d2 || !d_out) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
     if ((reinterpret_cast<uintptr_t>(d1) | reinterpret_cast<uintptr_t>(d2) | reinterpret_cast<uintptr_t>(d_out)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    Context *ctx = current();           // makes the context's device current: the launch must not land on whatever
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;   // device the calling thread happened to have selected
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
-    return launch_device(d1, d2, n, sm, gap, d_out, st, packed);
+    return launch_device(*ctx, d1, d2, n, sm, gap, d_out, st, packed);
 }
 
 int swmi_score_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, const int8_t score_matrix[16],
@@ -456,6 +539,20 @@ static int check_banded(const int8_t *sm, int len, int open, int ext)
     return SWMI_OK;
 }
 
+static int banded_device(Context &ctx, const void *d_seq1s, const void *d_seq2s, size_t n, int len, const int8_t *sm,
+                         int gap_open, int gap_extend, void *d_scores, hipStream_t stream)
+{
+    const SmRows rows = pack_rows(sm, 0);
+    const size_t max_launch = size_t(1) << 24;
+    for (size_t off = 0; off < n; off += max_launch) {
+        const size_t m = n - off < max_launch ? n - off : max_launch;
+        HIP_TRY(swmi::launch_banded_affine(static_cast<const uint8_t *>(d_seq1s) + off * size_t(len),
+                                           static_cast<const uint8_t *>(d_seq2s) + off * size_t(len),
+                                           static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend, stream));
+    }
+    return SWMI_OK;
+}
+
 int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, size_t n, int len,
                                     const int8_t score_matrix[16], int gap_open, int gap_extend, void *d_scores, void *stream)
 {
@@ -463,18 +560,9 @@ int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, si
     if (rc != SWMI_OK) return rc;
     if (n == 0) return SWMI_OK;
     if (!d_seq1s || !d_seq2s || !d_scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    const SmRows rows = pack_rows(score_matrix, 0);
-    const size_t max_launch = size_t(1) << 24;
-    for (size_t off = 0; off < n; off += max_launch) {
-        const size_t m = n - off < max_launch ? n - off : max_launch;
-        HIP_TRY(swmi::launch_banded_affine(static_cast<const uint8_t *>(d_seq1s) + off * size_t(len),
-                                           static_cast<const uint8_t *>(d_seq2s) + off * size_t(len),
-                                           static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend,
-                                           static_cast<hipStream_t>(stream)));
-    }
-    return SWMI_OK;
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    return banded_device(*ctx, d_seq1s, d_seq2s, n, len, score_matrix, gap_open, gap_extend, d_scores, static_cast<hipStream_t>(stream));
 }
 
 int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int len, const int8_t score_matrix[16],
@@ -484,30 +572,36 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
     if (rc != SWMI_OK) return rc;
     if (n == 0) return SWMI_OK;
     if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    std::lock_guard<std::mutex> lock(g_ctx.mu);
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     // the slot buffers are sized in 128-byte pairs: a len-mer pair occupies ceil(len / 128) of them
     const size_t per = (size_t(len) + kSeq - 1) / kSeq;
     const size_t chunk_cap = kChunkPairs / per;
     const size_t chunk = n < chunk_cap ? n : chunk_cap;
     for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
-        rc = ensure_slot(g_ctx.slots[k], chunk * per);
+        rc = ensure_slot(ctx->slots[k], chunk * per);
         if (rc != SWMI_OK) return rc;
     }
     size_t idx = 0;
-    for (size_t off = 0; off < n; off += chunk, ++idx) {
-        Slot &s = g_ctx.slots[idx % kSlots];
+    hipError_t e = hipSuccess;
+    rc = SWMI_OK;
+    for (size_t off = 0; off < n && e == hipSuccess && rc == SWMI_OK; off += chunk, ++idx) {
+        Slot &s = ctx->slots[idx % kSlots];
         const size_t m = n - off < chunk ? n - off : chunk;
-        HIP_TRY(hipMemcpyAsync(s.d_seq1, seq1s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream));
-        HIP_TRY(hipMemcpyAsync(s.d_seq2, seq2s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream));
-        rc = swmi_score_banded_affine_device(s.d_seq1, s.d_seq2, m, len, score_matrix, gap_open, gap_extend, s.d_scores, s.stream);
-        if (rc != SWMI_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(scores + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+        e = hipMemcpyAsync(s.d_seq1, seq1s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.d_seq2, seq2s + off * size_t(len), m * size_t(len), hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) rc = banded_device(*ctx, s.d_seq1, s.d_seq2, m, len, score_matrix, gap_open, gap_extend, s.d_scores, s.stream);
+        if (e == hipSuccess && rc == SWMI_OK)
+            e = hipMemcpyAsync(scores + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
     }
     for (int k = 0; k < kSlots; ++k)
-        if (g_ctx.slots[k].stream) HIP_TRY(hipStreamSynchronize(g_ctx.slots[k].stream));
+        if (ctx->slots[k].stream) {
+            const hipError_t es = hipStreamSynchronize(ctx->slots[k].stream);    // also after a failure: the caller's buffers are in use
+            if (e == hipSuccess) e = es;
+        }
+    if (rc != SWMI_OK) return rc;
+    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_score_banded_affine: %s", hipGetErrorString(e));
     return SWMI_OK;
 }
 
@@ -517,24 +611,30 @@ static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n,
     if (n == 0) return SWMI_OK;
     if (!d_seq1s || !d_seq2s || !d_scores || !d_lengths || (!d_tracebacks && cap != 0))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2s) | reinterpret_cast<uintptr_t>(d_scores) |
+         reinterpret_cast<uintptr_t>(d_lengths) | reinterpret_cast<uintptr_t>(d_tracebacks)) & 15)
+        return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned (the kernels use 16-byte loads and 8-byte stores)");
     if (n > (size_t(1) << 18)) return fail(SWMI_ERR_INVALID_ARGUMENT, "at most 2^18 alignments per call (got %zu)", n);
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    {
-        std::lock_guard<std::mutex> lock(g_ctx.mu);
-        const size_t need = swmi::semiglobal_workspace_bytes(n);
-        if (need > g_ctx.sg_workspace_bytes) {
-            HIP_TRY(hipDeviceSynchronize());              // the old workspace may still be in use by an earlier launch
-            if (g_ctx.sg_workspace) (void)hipFree(g_ctx.sg_workspace);
-            g_ctx.sg_workspace = nullptr;
-            g_ctx.sg_workspace_bytes = 0;
-            HIP_TRY(hipMalloc(&g_ctx.sg_workspace, need));
-            g_ctx.sg_workspace_bytes = need;
-        }
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // The workspace belongs to (context, stream): calls on one stream serialise by themselves, calls on different streams
+    // get different workspaces.  Lookup, growth and the launch happen under one lock, so a concurrent call can never free
+    // a workspace between this call's lookup and its launch; growing synchronises only this stream.
+    std::lock_guard<std::mutex> lock(ctx->ws_mu);
+    Workspace &ws = ctx->sg_workspaces[st];
+    const size_t need = swmi::semiglobal_workspace_bytes(n);
+    if (need > ws.bytes) {
+        HIP_TRY(hipStreamSynchronize(st));                // earlier launches on this stream may still use the old one
+        if (ws.ptr) (void)hipFree(ws.ptr);
+        ws.ptr = nullptr;
+        ws.bytes = 0;
+        HIP_TRY(hipMalloc(&ws.ptr, need));
+        ws.bytes = need;
     }
-    HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n,
-                                    g_ctx.sg_workspace, static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks),
-                                    cap, static_cast<uint32_t *>(d_lengths), static_cast<hipStream_t>(stream), between));
+    HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n, ws.ptr,
+                                    static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks), cap,
+                                    static_cast<uint32_t *>(d_lengths), st, between, ctx->prop.multiProcessorCount));
     return SWMI_OK;
 }
 
@@ -544,13 +644,33 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
     return semiglobal_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, nullptr);
 }
 
+int swmi_semiglobal_release_workspaces(void)
+{
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(ctx->ws_mu);
+    for (auto &w : ctx->sg_workspaces)
+        if (w.second.ptr) (void)hipFree(w.second.ptr);
+    ctx->sg_workspaces.clear();
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_kernels_for_batch(size_t n, char *sweep, size_t sweep_len, char *traceback, size_t traceback_len)
+{
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    swmi::semiglobal_kernel_names(n, ctx->prop.multiProcessorCount, sweep, sweep_len, traceback, traceback_len);
+    return SWMI_OK;
+}
+
 int swmi_semiglobal_time_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
                                 size_t cap, void *d_lengths, void *stream, float phase_ms[2])
 {
     if (!phase_ms) return fail(SWMI_ERR_INVALID_ARGUMENT, "phase_ms is NULL");
     if (n == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "n is 0");
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
+    int rc = SWMI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipError_t he = hipSuccess;
@@ -573,18 +693,17 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     if (n == 0) return SWMI_OK;
     if (!seq1s || !seq2s || !scores || !lengths || (!tracebacks && cap != 0))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    std::lock_guard<std::mutex> lock(g_ctx.mu);
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     constexpr size_t kLen = SWMI_SG_LEN;
     // Chunks of up to 8192 alignments (~0.35 MB of workspace + cap*8 B of output each), two sets of device buffers: while
     // the host is busy receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k+1.
     const size_t chunk = n < 8192 ? n : 8192;
-    using Set = Context::SgSet;
-    Set *sets = g_ctx.sg_sets;
+    using Set = SgSet;
+    Set *sets = ctx->sg_sets;
     const int n_sets = n > chunk ? 2 : 1;
-    hipStream_t streams[2] = {g_ctx.slots[0].stream, g_ctx.slots[1].stream};
+    hipStream_t streams[2] = {ctx->slots[0].stream, ctx->slots[1].stream};
     hipError_t e = hipSuccess;
     for (int k = 0; k < n_sets && e == hipSuccess; ++k) {
         Set &s = sets[k];
@@ -638,7 +757,8 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
         s.m = n - off < chunk ? n - off : chunk;
         e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st);
+        if (e == hipSuccess)
+            e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st, nullptr, ctx->prop.multiProcessorCount);
         if (e == hipSuccess && n_sets == 2) e = drain(turn ^ 1);         // the previous chunk, while this one computes
     }
     for (int k = 0; k < n_sets; ++k) {
@@ -654,22 +774,24 @@ int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
 {
     if (n_seqs == 0) return SWMI_OK;
     if (!packed || !unpacked) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seqs = %zu", n_seqs);
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    std::lock_guard<std::mutex> lock(g_ctx.mu);
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    std::lock_guard<std::mutex> lock(ctx->mu);
     // reuse slot 0: seq1 buffer holds the packed bytes, seq2 buffer the unpacked ones
     const size_t chunk = n_seqs < kChunkPairs ? n_seqs : kChunkPairs;
-    rc = ensure_slot(g_ctx.slots[0], chunk);
+    int rc = ensure_slot(ctx->slots[0], chunk);
     if (rc != SWMI_OK) return rc;
-    Slot &s = g_ctx.slots[0];
-    for (size_t off = 0; off < n_seqs; off += chunk) {
+    Slot &s = ctx->slots[0];
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < n_seqs && e == hipSuccess; off += chunk) {
         const size_t m = n_seqs - off < chunk ? n_seqs - off : chunk;
-        HIP_TRY(hipMemcpyAsync(s.d_seq1, packed + off * SWMI_PACKED_LEN, m * SWMI_PACKED_LEN, hipMemcpyHostToDevice, s.stream));
-        HIP_TRY(swmi::launch_unpack(s.d_seq1, s.d_seq2, m, s.stream));
-        HIP_TRY(hipMemcpyAsync(unpacked + off * kSeq, s.d_seq2, m * kSeq, hipMemcpyDeviceToHost, s.stream));
-        HIP_TRY(hipStreamSynchronize(s.stream));
+        e = hipMemcpyAsync(s.d_seq1, packed + off * SWMI_PACKED_LEN, m * SWMI_PACKED_LEN, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = swmi::launch_unpack(s.d_seq1, s.d_seq2, m, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(unpacked + off * kSeq, s.d_seq2, m * kSeq, hipMemcpyDeviceToHost, s.stream);
+        const hipError_t es = hipStreamSynchronize(s.stream);              // also after a failure: the caller's buffers are in use
+        if (e == hipSuccess) e = es;
     }
+    if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_unpack: %s", hipGetErrorString(e));
     return SWMI_OK;
 }
 
@@ -679,8 +801,7 @@ int swmi_generate_pairs_device(void *d_seq1s, void *d_seq2s, size_t n, uint64_t 
     if (!d_seq1s || !d_seq2s) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
     if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2s)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     HIP_TRY(swmi::launch_generate(static_cast<uint8_t *>(d_seq1s), static_cast<uint8_t *>(d_seq2s), n, seed, first_pair, st));
     return SWMI_OK;
@@ -714,8 +835,8 @@ int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, c
                            int8_t gap_penalty, void *d_scores, void *stream, int iters, float *avg_ms)
 {
     if (!avg_ms || iters <= 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "avg_ms is NULL or iters <= 0");
-    int rc = check_ready();
-    if (rc != SWMI_OK) return rc;
+    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
+    int rc = SWMI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t he = hipEventCreate(&e0);
@@ -744,11 +865,11 @@ int swmi_queue_create(size_t max_pairs, const int8_t score_matrix[16], int8_t ga
     int rc = check_params(score_matrix, gap_penalty);
     if (rc != SWMI_OK) return rc;
     if (max_pairs == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "max_pairs is 0");
-    rc = check_ready();
-    if (rc != SWMI_OK) return rc;
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    Context *ctx = current();
+    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
     swmi_queue *q = new (std::nothrow) swmi_queue;
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "out of host memory");
+    q->ctx = ctx;
     q->max_pairs = max_pairs;
     memcpy(q->sm, score_matrix, 16);
     q->gap = gap_penalty;
@@ -786,8 +907,9 @@ int swmi_queue_wait(swmi_queue *q, const int32_t **scores, size_t *n_scores)
 {
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "queue is NULL");
     int rc = queue_ship(q, q->count);
+    const hipError_t es = hipStreamSynchronize(q->stream);       // on failure too: shipments in flight read the staging memory
     if (rc != SWMI_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(q->stream));
+    if (es != hipSuccess) return fail(SWMI_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
     if (scores) *scores = q->h_scores;
     if (n_scores) *n_scores = q->count;
     return SWMI_OK;
@@ -804,6 +926,7 @@ int swmi_queue_reset(swmi_queue *q)
 int swmi_queue_destroy(swmi_queue *q)
 {
     if (!q) return SWMI_OK;
+    if (q->ctx) (void)hipSetDevice(q->ctx->device);
     if (q->stream) (void)hipStreamSynchronize(q->stream);
     if (q->h_seq1) (void)hipHostFree(q->h_seq1);
     if (q->h_seq2) (void)hipHostFree(q->h_seq2);

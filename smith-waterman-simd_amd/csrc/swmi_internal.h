@@ -45,6 +45,9 @@ bool schedule_supported(int lanes_per_alignment);
 size_t semiglobal_workspace_bytes(size_t n);
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
-                             hipEvent_t between = nullptr);   // recorded between the sweep and the traceback kernel
+                             hipEvent_t between = nullptr,    // recorded between the sweep and the traceback kernel
+                             int compute_units = 256);        // of the device: picks the sweep mapping (wavefronts per SIMD)
+// Names of the sweep / traceback kernels launch_semiglobal picks for n alignments on a device with that many CUs.
+void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len);
 
 }  // namespace swmi

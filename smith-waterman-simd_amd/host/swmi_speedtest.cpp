@@ -6,6 +6,9 @@
 //   queued     : the same 1,000,000 calls submitted through swmi::PairQueue (host batches, GPU scores)
 //   batch      : one swmi_score_batch() over 1M DISTINCT pairs (counter-based generator), host buffers
 //   device     : swmi_time_batch_device() on inputs resident in HBM (kernel only)
+//   N-gpu      : the same loop pointed at every GPU of the node from this ONE process (swmi_init_all): the host batch
+//                split by swmi_score_batch_multi, and resident shards scored + gathered by swmi_sharded_*
+//                (SWMI_SPEEDTEST_DEVICES=0,0 binds a list instead -- two contexts on one GPU rehearse the path)
 // No CPU scoring happens in this program; the CPU baseline is timed by bench.py's cpu_baseline leg.
 #include <chrono>
 #include <cstdio>
@@ -165,5 +168,71 @@ int main(int argc, char **argv)
         (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dsc); (void)hipFree(dlen); (void)hipFree(dtb);
     }
     swmi_shutdown();
+
+    // == the 1M-call loop of SpeedTest (source.cpp:3074-3082) over every GPU of the node, driven by this one process
+    {
+        int G = 0;
+        if (const char *list = getenv("SWMI_SPEEDTEST_DEVICES")) {
+            std::vector<int> devs;
+            for (const char *p = list; *p;) {
+                devs.push_back(atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+            G = swmi_init_devices(devs.data(), (int)devs.size());
+        } else {
+            G = swmi_init_all(0);
+        }
+        if (G <= 0) die("swmi_init_all");
+        printf("== SpeedTest (10,-30,15) on %d GPU context(s) from one process\n", G);
+        std::array<int8_t, 16> sm;
+        for (int i = 0; i < 16; ++i) sm[i] = int8_t(i % 5 == 0 ? 10 : -30);
+        const int8_t gap = 15;
+        long long want_sum = 0;
+        {
+            std::vector<uint8_t> s1(n * 128), s2(n * 128);
+            std::vector<int32_t> out(n);
+            swmi_generate_pairs_host(s1.data(), s2.data(), n, 10000, 0);
+            if (swmi_score_batch_multi(s1.data(), s2.data(), n, sm.data(), gap, out.data()) != SWMI_OK) die("swmi_score_batch_multi");
+            const double t0 = now_ms();
+            if (swmi_score_batch_multi(s1.data(), s2.data(), n, sm.data(), gap, out.data()) != SWMI_OK) die("swmi_score_batch_multi");
+            const double ms = now_ms() - t0;
+            for (int32_t s : out) want_sum += s;
+            printf("mi355x %d-gpu batch version: %.1f ms / %.0fM distinct pairs incl. PCIe  (%.1f M alignments/s, checksum %lld)\n", G, ms,
+                   n / 1e6, n / ms / 1e3, want_sum);
+        }
+        const size_t per_gpu[2] = {n, argc > 4 ? strtoull(argv[4], nullptr, 10) : 0};   // argv[4]: a second, larger size per GPU (e.g. 67108864)
+        for (size_t pg : per_gpu) {
+            if (pg == 0) continue;
+            const size_t total = pg * size_t(G);
+            swmi_sharded_batch *sb = nullptr;
+            if (swmi_sharded_create(total, 0, &sb) != SWMI_OK) die("swmi_sharded_create");
+            if (swmi_sharded_generate(sb, 10000, 0) != SWMI_OK) die("swmi_sharded_generate");
+            std::vector<float> k_ms(G), g_ms(G);
+            double wall = 0;
+            for (int mode : {SWMI_GATHER_NONE, SWMI_GATHER_ROOT, SWMI_GATHER_ALL}) {
+                if (swmi_sharded_time(sb, sm.data(), gap, mode, 3, nullptr, nullptr, nullptr) != SWMI_OK) die("warmup");
+                if (swmi_sharded_time(sb, sm.data(), gap, mode, 20, k_ms.data(), g_ms.data(), &wall) != SWMI_OK) die("swmi_sharded_time");
+                float kmax = 0, gmax = 0;
+                for (int g = 0; g < G; ++g) { kmax = k_ms[g] > kmax ? k_ms[g] : kmax; gmax = g_ms[g] > gmax ? g_ms[g] : gmax; }
+                printf("mi355x %d-gpu device version: %.3f ms / %.0fM per GPU, %s  (%.1f M alignments/s whole job; slowest kernel %.3f ms, "
+                       "slowest gather %.3f ms)\n", G, wall, pg / 1e6,
+                       mode == SWMI_GATHER_NONE ? "scores left sharded" : mode == SWMI_GATHER_ROOT ? "gathered to GPU 0 (peer DMA)"
+                   : swmi_sharded_gather_backend(sb) == 2 ? "all-gathered (RCCL)" : "all-gathered (peer copies: a GPU is bound twice)",
+                       total / wall / 1e3, kmax, gmax);
+            }
+            if (pg == n) {      // the first shard-0-sized prefix of the gathered vector must be the host batch's scores
+                std::vector<int32_t> got(total);
+                if (swmi_sharded_gathered_host(sb, 0, got.data()) != SWMI_OK) die("swmi_sharded_gathered_host");
+                long long sum = 0;
+                for (size_t k = 0; k < n; ++k) sum += got[k];
+                printf("gathered vector: first %.0fM scores checksum %lld (%s the host batch)\n", n / 1e6, sum,
+                       sum == want_sum ? "equals" : "DIFFERS FROM");
+                if (sum != want_sum) return 1;
+            }
+            swmi_sharded_destroy(sb);
+        }
+        swmi_shutdown();
+    }
     return 0;
 }

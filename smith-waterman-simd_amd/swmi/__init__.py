@@ -58,6 +58,25 @@ def load():
     vp, sz, u64, i8 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_int8
     lib.swmi_last_error.restype = ctypes.c_char_p
     lib.swmi_init.argtypes = [ctypes.c_int]
+    lib.swmi_init_all.argtypes = [ctypes.c_int]
+    lib.swmi_init_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.swmi_use_gpu.argtypes = [ctypes.c_int]
+    lib.swmi_shard_bounds.argtypes = [sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.swmi_score_batch_multi.argtypes = [vp, vp, sz, vp, i8, vp]
+    lib.swmi_score_batch_packed_multi.argtypes = [vp, vp, sz, vp, i8, vp]
+    lib.swmi_sharded_create.argtypes = [sz, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.swmi_sharded_destroy.argtypes = [vp]
+    lib.swmi_sharded_generate.argtypes = [vp, u64, u64]
+    lib.swmi_sharded_upload.argtypes = [vp, vp, vp]
+    lib.swmi_sharded_score.argtypes = [vp, vp, i8, ctypes.c_int]
+    lib.swmi_sharded_wait.argtypes = [vp]
+    lib.swmi_sharded_scores_host.argtypes = [vp, vp]
+    lib.swmi_sharded_gathered_device.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.swmi_sharded_gather_backend.argtypes = [vp]
+    lib.swmi_sharded_gathered_host.argtypes = [vp, ctypes.c_int, vp]
+    lib.swmi_sharded_time.argtypes = [vp, vp, i8, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+    lib.swmi_semiglobal_kernels_for_batch.argtypes = [sz, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
     lib.swmi_score_pair.argtypes = [vp, vp, vp, i8]
     lib.swmi_score_batch.argtypes = [vp, vp, sz, vp, i8, vp]
     lib.swmi_score_batch_device.argtypes = [vp, vp, sz, vp, i8, vp, vp]
@@ -102,10 +121,21 @@ def _u8(a, shape_last):
 
 
 def _sm(score_matrix):
-    sm = np.ascontiguousarray(score_matrix, dtype=np.int8).reshape(-1)
-    if sm.size != 16:
+    raw = np.asarray(score_matrix).reshape(-1)
+    if raw.size != 16:
         raise ValueError("score_matrix must have 16 entries")
-    return sm
+    if raw.dtype != np.int8 and (raw.min() < -128 or raw.max() > 127):   # the cast below would wrap silently
+        raise SwmiError(ERR_DOMAIN, "score_matrix entries must lie in [-128, 127] (got %d..%d)" % (raw.min(), raw.max()))
+    return np.ascontiguousarray(raw, dtype=np.int8)
+
+
+def _gap(gap_penalty):
+    """ctypes converts to int8 without an overflow check (256 would score as gap 0): check the range here, so that the
+    C side's domain check sees what the caller meant."""
+    g = int(gap_penalty)
+    if g < -128 or g > 127:
+        raise SwmiError(ERR_DOMAIN, "gap_penalty %d is outside the supported domain [0,127]" % g)
+    return g
 
 
 def match_matrix(match, mismatch):
@@ -119,8 +149,35 @@ def init(device=-1):
     _check(load().swmi_init(device))
 
 
+def init_all(n_gpus=0):
+    """Bind the first n_gpus visible GPUs (0 = all) in this one process; returns the number bound."""
+    return _check(load().swmi_init_all(n_gpus))
+
+
+def init_devices(devices):
+    """Bind an explicit device list (a device may repeat: two contexts on one GPU)."""
+    arr = (ctypes.c_int * len(devices))(*devices)
+    return _check(load().swmi_init_devices(arr, len(devices)))
+
+
+def num_gpus():
+    return int(load().swmi_num_gpus())
+
+
+def use_gpu(index):
+    """Select which bound GPU this thread's single-GPU calls address."""
+    _check(load().swmi_use_gpu(index))
+
+
 def shutdown():
     _check(load().swmi_shutdown())
+
+
+def shard_bounds(n, shard, n_shards):
+    """[lo, hi) of shard `shard` of `n_shards` -- the C library's rule (swmi_shard_bounds), same as sharding.shard_bounds."""
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(load().swmi_shard_bounds(n, shard, n_shards, ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
 
 
 def last_error():
@@ -153,7 +210,7 @@ def device_info():
 def score_pair(seq1, seq2, score_matrix, gap_penalty):
     """Mirror of SmithWaterman_simd4(seq1, seq2, score_matrix, gap_penalty) (source.cpp:462-466)."""
     a, b, sm = _u8(seq1, SEQ_LEN), _u8(seq2, SEQ_LEN), _sm(score_matrix)
-    return _check(load().swmi_score_pair(a.ctypes.data, b.ctypes.data, sm.ctypes.data, int(gap_penalty)))
+    return _check(load().swmi_score_pair(a.ctypes.data, b.ctypes.data, sm.ctypes.data, _gap(gap_penalty)))
 
 
 def score_batch(seq1s, seq2s, score_matrix, gap_penalty):
@@ -162,15 +219,93 @@ def score_batch(seq1s, seq2s, score_matrix, gap_penalty):
         raise ValueError("seq1s and seq2s must have the same shape")
     n = a.size // SEQ_LEN
     out = np.zeros(n, np.int32)
-    _check(load().swmi_score_batch(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    _check(load().swmi_score_batch(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
+
+
+def score_batch_multi(seq1s, seq2s, score_matrix, gap_penalty, packed=False):
+    """swmi_score_batch[_packed]_multi: the host batch split over every bound GPU (init_all / init_devices)."""
+    width = PACKED_LEN if packed else SEQ_LEN
+    a, b, sm = _u8(seq1s, width), _u8(seq2s, width), _sm(score_matrix)
+    if a.shape != b.shape:
+        raise ValueError("seq1s and seq2s must have the same shape")
+    n = a.size // width
+    out = np.zeros(n, np.int32)
+    fn = load().swmi_score_batch_packed_multi if packed else load().swmi_score_batch_multi
+    _check(fn(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
+    return out
+
+
+GATHER_NONE, GATHER_ROOT, GATHER_ALL = 0, 1, 2
+
+
+class ShardedBatch:
+    """A batch whose shards stay resident on the bound GPUs (swmi_sharded_* in include/swmi.h)."""
+
+    def __init__(self, n, packed=False):
+        self._b = ctypes.c_void_p()
+        self.n = n
+        _check(load().swmi_sharded_create(n, 1 if packed else 0, ctypes.byref(self._b)))
+
+    def generate(self, seed, first_pair=0):
+        _check(load().swmi_sharded_generate(self._b, seed, first_pair))
+
+    def upload(self, seq1s, seq2s):
+        a = np.ascontiguousarray(seq1s, dtype=np.uint8)
+        b = np.ascontiguousarray(seq2s, dtype=np.uint8)
+        _check(load().swmi_sharded_upload(self._b, a.ctypes.data, b.ctypes.data))
+
+    def score(self, score_matrix, gap_penalty, gather=GATHER_NONE):
+        sm = _sm(score_matrix)
+        _check(load().swmi_sharded_score(self._b, sm.ctypes.data, _gap(gap_penalty), gather))
+
+    def wait(self):
+        _check(load().swmi_sharded_wait(self._b))
+
+    def scores(self):
+        out = np.zeros(self.n, np.int32)
+        _check(load().swmi_sharded_scores_host(self._b, out.ctypes.data))
+        return out
+
+    def gathered_ptr(self, index=0):
+        p = ctypes.c_void_p()
+        _check(load().swmi_sharded_gathered_device(self._b, index, ctypes.byref(p)))
+        return p.value
+
+    def gather_backend(self):
+        return {0: "undecided", 1: "p2p", 2: "rccl"}[_check(load().swmi_sharded_gather_backend(self._b))]
+
+    def gathered(self, index=0):
+        """The full score vector GPU `index` holds after a gather, copied to the host."""
+        out = np.zeros(self.n, np.int32)
+        _check(load().swmi_sharded_gathered_host(self._b, index, out.ctypes.data))
+        return out
+
+    def time(self, score_matrix, gap_penalty, gather=GATHER_NONE, iters=10):
+        """({"kernel_ms": [...], "gather_ms": [...], "wall_ms": float}) averaged over `iters` back-to-back calls."""
+        g = num_gpus()
+        k, ga, w = (ctypes.c_float * g)(), (ctypes.c_float * g)(), ctypes.c_double()
+        sm = _sm(score_matrix)
+        _check(load().swmi_sharded_time(self._b, sm.ctypes.data, _gap(gap_penalty), gather, iters, k, ga, ctypes.byref(w)))
+        return {"kernel_ms": [float(x) for x in k], "gather_ms": [float(x) for x in ga], "wall_ms": float(w.value)}
+
+    def close(self):
+        if self._b:
+            load().swmi_sharded_destroy(self._b)
+            self._b = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def score_one_vs_many(seq1s, seq2, score_matrix, gap_penalty):
     a, b, sm = _u8(seq1s, SEQ_LEN), _u8(seq2, SEQ_LEN), _sm(score_matrix)
     n = a.size // SEQ_LEN
     out = np.zeros(n, np.int32)
-    _check(load().swmi_score_one_vs_many(a.ctypes.data, n, b.ctypes.data, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    _check(load().swmi_score_one_vs_many(a.ctypes.data, n, b.ctypes.data, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
 
 
@@ -178,7 +313,7 @@ def score_batch_packed(seq1s_packed, seq2s_packed, score_matrix, gap_penalty):
     a, b, sm = _u8(seq1s_packed, PACKED_LEN), _u8(seq2s_packed, PACKED_LEN), _sm(score_matrix)
     n = a.size // PACKED_LEN
     out = np.zeros(n, np.int32)
-    _check(load().swmi_score_batch_packed(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, int(gap_penalty), out.ctypes.data))
+    _check(load().swmi_score_batch_packed(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
 
 
@@ -209,7 +344,8 @@ SG_MAX_TRACEBACK = 32769
 def semiglobal_xdrop(seq1s, seq2s, cap=SG_MAX_TRACEBACK):
     """Mirror of SemiGlobal_AdaptiveBanded_XDrop_111_32_70 (source.cpp:1836-1976) for n pairs of 16384-mers.
 
-    Returns (scores[n], list of n (len_k, 2) int32 arrays = the reference's traceback vectors)."""
+    Returns (scores[n], list of n (len_k, 2) int32 arrays = the reference's traceback vectors, lengths[n] = the
+    reference's .second.size() per alignment, which exceeds len_k only when `cap` cut the traceback short)."""
     a = np.ascontiguousarray(seq1s, dtype=np.uint8).reshape(-1, SG_LEN)
     b = np.ascontiguousarray(seq2s, dtype=np.uint8).reshape(-1, SG_LEN)
     n = a.shape[0]
@@ -232,6 +368,13 @@ def semiglobal_time_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_l
     return float(ms[0]), float(ms[1])
 
 
+def semiglobal_kernels_for_batch(n):
+    """(sweep kernel name, traceback kernel name) a call with n alignments runs on the current GPU."""
+    a, b = ctypes.create_string_buffer(96), ctypes.create_string_buffer(96)
+    _check(load().swmi_semiglobal_kernels_for_batch(n, a, 96, b, 96))
+    return a.value.decode(), b.value.decode()
+
+
 def unpack(packed):
     p = _u8(packed, PACKED_LEN)
     n = p.size // PACKED_LEN
@@ -250,12 +393,12 @@ def score_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores,
     """Device pointers (ints). Asynchronous on `stream` (a hipStream_t value, 0 = the HIP null stream)."""
     sm = _sm(score_matrix)
     fn = load().swmi_score_batch_packed_device if packed else load().swmi_score_batch_device
-    _check(fn(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream))
+    _check(fn(d_seq1s, d_seq2s, n, sm.ctypes.data, _gap(gap_penalty), d_scores, stream))
 
 
 def score_one_vs_many_device(d_seq1s, n, d_seq2, score_matrix, gap_penalty, d_scores, stream=0):
     sm = _sm(score_matrix)
-    _check(load().swmi_score_one_vs_many_device(d_seq1s, n, d_seq2, sm.ctypes.data, int(gap_penalty), d_scores, stream))
+    _check(load().swmi_score_one_vs_many_device(d_seq1s, n, d_seq2, sm.ctypes.data, _gap(gap_penalty), d_scores, stream))
 
 
 def generate_pairs_device(d_seq1s, d_seq2s, n, seed, first_pair=0, stream=0):
@@ -272,7 +415,7 @@ def generate_pairs_host(n, seed, first_pair=0):
 def time_batch_device(d_seq1s, d_seq2s, n, score_matrix, gap_penalty, d_scores, stream=0, iters=10):
     sm = _sm(score_matrix)
     ms = ctypes.c_float()
-    _check(load().swmi_time_batch_device(d_seq1s, d_seq2s, n, sm.ctypes.data, int(gap_penalty), d_scores, stream, iters,
+    _check(load().swmi_time_batch_device(d_seq1s, d_seq2s, n, sm.ctypes.data, _gap(gap_penalty), d_scores, stream, iters,
                                          ctypes.byref(ms)))
     return ms.value
 
@@ -283,7 +426,7 @@ class Queue:
     def __init__(self, max_pairs, score_matrix, gap_penalty):
         self._q = ctypes.c_void_p()
         sm = _sm(score_matrix)
-        _check(load().swmi_queue_create(max_pairs, sm.ctypes.data, int(gap_penalty), ctypes.byref(self._q)))
+        _check(load().swmi_queue_create(max_pairs, sm.ctypes.data, _gap(gap_penalty), ctypes.byref(self._q)))
 
     def submit(self, seq1, seq2):
         a, b = _u8(seq1, SEQ_LEN), _u8(seq2, SEQ_LEN)

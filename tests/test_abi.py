@@ -22,7 +22,11 @@ def test_header_declares_the_expected_surface():
                  "swmi_queue_create", "swmi_queue_submit", "swmi_queue_wait", "swmi_queue_destroy",
                  "swmi_set_schedule", "swmi_generate_pairs_device", "swmi_generate_pairs_host",
                  "swmi_time_batch_device", "swmi_get_device_info", "swmi_score_banded_affine",
-                 "swmi_score_banded_affine_device", "swmi_semiglobal_xdrop", "swmi_semiglobal_xdrop_device"):
+                 "swmi_score_banded_affine_device", "swmi_semiglobal_xdrop", "swmi_semiglobal_xdrop_device",
+                 "swmi_init_all", "swmi_init_devices", "swmi_use_gpu", "swmi_num_gpus", "swmi_shard_bounds",
+                 "swmi_score_batch_multi", "swmi_score_batch_packed_multi", "swmi_sharded_create", "swmi_sharded_score",
+                 "swmi_sharded_wait", "swmi_sharded_scores_host", "swmi_sharded_gathered_device", "swmi_sharded_time",
+                 "swmi_sharded_destroy", "swmi_semiglobal_kernels_for_batch", "swmi_semiglobal_release_workspaces"):
         assert must in syms
 
 
@@ -30,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(PKG, "lib", "libswmi.so"))
     for name in _declared_symbols():
         assert hasattr(lib, name), "libswmi.so does not export %s" % name
-    assert lib.swmi_version() == 100
+    assert lib.swmi_version() == 200
 
 
 def test_product_library_does_not_link_the_oracle():
@@ -58,6 +62,47 @@ def test_argument_errors_do_not_need_a_device(swmi_mod):
     assert lib.swmi_score_batch(None, a.ctypes.data, 1, sm.ctypes.data, 15, out.ctypes.data) == swmi_mod.ERR_INVALID_ARGUMENT
     assert lib.swmi_set_schedule(3, 0) == swmi_mod.ERR_INVALID_ARGUMENT
     assert lib.swmi_set_schedule(8, 0) == swmi_mod.OK
+
+
+def test_c_shard_rule_is_the_python_shard_rule(swmi_mod):
+    """swmi_shard_bounds (what swmi_score_batch_multi / swmi_sharded_* split by, swmi_multi.cpp) and
+    sharding.shard_bounds (what bench.py's ranks split by) are one rule; needs no device."""
+    from swmi import sharding
+    for n in (0, 1, 7, 8, 9, 1000003, 1 << 20, (1 << 29) + 3):
+        for world in (1, 2, 3, 4, 7, 8):
+            c = [swmi_mod.shard_bounds(n, r, world) for r in range(world)]
+            assert c == [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert c[0][0] == 0 and c[-1][1] == n
+            assert all(h0 == l1 for (_, h0), (l1, _) in zip(c, c[1:]))
+    with pytest.raises(swmi_mod.SwmiError):
+        swmi_mod.shard_bounds(10, 2, 2)
+
+
+def test_python_binding_rejects_values_ctypes_would_wrap(swmi_mod):
+    a = np.zeros((1, 128), np.uint8)
+    for bad_gap in (256, 300, -129, 128 + 256):
+        with pytest.raises(swmi_mod.SwmiError) as e:
+            swmi_mod.score_batch(a, a, match_matrix(1, -1), bad_gap)
+        assert e.value.code == swmi_mod.ERR_DOMAIN
+    with pytest.raises(swmi_mod.SwmiError) as e:
+        swmi_mod.score_batch(a, a, np.full(16, 200, np.int32), 1)       # would wrap to -56 in an int8 cast
+    assert e.value.code == swmi_mod.ERR_DOMAIN
+
+
+def test_multi_gpu_entry_points_without_a_device_fail_loudly(swmi_mod):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the no-device behaviour is covered on the CPU runner")
+    lib = swmi_mod.load()
+    assert lib.swmi_init_all(0) == swmi_mod.ERR_NO_DEVICE
+    assert swmi_mod.num_gpus() == 0
+    a = np.zeros((70, 128), np.uint8)
+    with pytest.raises(swmi_mod.SwmiError) as e:
+        swmi_mod.score_batch_multi(a, a, match_matrix(1, -1), 1)
+    assert e.value.code == swmi_mod.ERR_NOT_INITIALIZED
+    with pytest.raises(swmi_mod.SwmiError) as e:
+        swmi_mod.ShardedBatch(1000)
+    assert e.value.code == swmi_mod.ERR_NOT_INITIALIZED
 
 
 def test_scoring_without_a_device_fails_loudly(swmi_mod):
