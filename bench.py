@@ -3,18 +3,32 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--lanes L]
 
-A "step" is one pass of the hot path over one batch of synthetic pairs: every rank scores its own P pairs
-(P = 1,048,576 by default = BASELINE.json configs[1], "1M same-shape pairs on 1 MI355X") that are already
-resident in HBM when the timed region starts, and -- for N > 1 -- the int32 scores are all-gathered over
-RCCL (the path's only exchange step).  Weak scaling: per-GPU work is fixed as N grows.
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-(one rank per GPU); started plainly with --gpus N > 1 the script spawns that launcher as a child process.
+A "step" is one pass of the hot path over one batch of synthetic pairs that are already resident in HBM when the timed
+region starts.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sw128_kernel), measured live with HIP
-events on the launch stream inside the timed region; `cpu_baseline` (N = 1 only) is the reference's own simd4
-(oracle/_ref/libswref.so, compiled from the reference sources in the build container) timed on ONE host core
-of this box on a bounded sample of the same generated pairs, which doubles as a bit-exactness check of the GPU
-scores.  The oracle / reference build are used here only as checker and baseline, never as the measured path.
+N = 1  every step scores P = 1,048,576 pairs (BASELINE.json configs[1], "1M same-shape pairs on 1 MI355X").  After the
+       headline the same invocation appends `rows` -- short runs of the other rows of SURVEY.md section 8 (L = 64 = one
+       wavefront per alignment, 2-bit packed input, one-vs-many, the semi-global X-drop aligner at 65,536 alignments, the
+       banded affine extension at 1024 x 1024), each with kernel_ms, its VALU issue-bound fraction and gpu_mismatches
+       against the reference / oracle -- and `sustained`, >= 2 s of back-to-back launches of the headline kernel.
+N > 1  one rank per GPU (the driver starts `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`;
+       started plainly with --gpus N > 1 the script spawns that launcher as a child).  Rank g scores the contiguous shard
+       g of N * P pairs, P = 67,108,864 per GPU by default (BASELINE.json configs[3]: "512M pairs sharded across
+       8 x MI355X, per-GPU sub-batch + RCCL gather"), and the int32 scores are all-gathered over RCCL (the path's only
+       exchange step) through swmi/sharding.py.  `value` = the leg with a gather after EVERY step
+       (asynchronous, overlapping the next step's kernel); `legs` also reports "one final gather", "no gather" and the
+       configs[1]-sized leg (1M pairs per GPU per step, gather every step), each with per-rank kernel_ms / gather_ms, and
+       rank 0 checks a sample of EVERY shard of the gathered vector against the CPU oracle (`gpu_mismatches`).
+       Weak scaling: per-GPU work is fixed as N grows (N = 1 runs the configs[1] size the metric is quoted on).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (sw128_kernel), timed live with HIP events on the
+launch stream inside the timed region.  `roofline.frac` is a utilisation: VALU issue cycles the kernel needs -- counted
+from the disassembly of the libswmi.so that is being timed (tools/isa_census.py: per-class instruction counts x the
+measured per-class issue cost, profiles/r01_microbench_valu_rate*.txt) -- divided by the SIMD cycles that elapsed
+(kernel time x 1024 SIMDs x 2.4 GHz).  `cpu_baseline` (N = 1 only) is the reference's own simd4
+(oracle/_ref/libswref.so, compiled from the reference sources in the build container) timed on ONE host core of this box
+on a bounded sample of the same generated pairs, which doubles as a bit-exactness check of the GPU scores.  The oracle /
+reference build are used here only as checker and baseline, never as the measured path.
 """
 import argparse
 import ctypes
@@ -27,16 +41,95 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "smith-waterman-simd_amd")
 sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 CELLS = 128 * 128
 INT_OPS_PER_ALIGNMENT = CELLS * 7          # 1 add, 2 sub, 4 max per cell (source.cpp:49-53)
 BYTES_PER_ALIGNMENT = 128 + 128 + 4
-# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate 32-bit integer lane-ops/s
-# (v_add_u32 / v_sub_u32 issue at 32 lanes/clk/SIMD; v_max_i32, v_max3_i32 and v_dot4 at half of that --
-#  tools/microbench/valu_rate*.hip).
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz: a SIMD issues one wave64 VALU instruction per 2 (full rate), 4 (half
+# rate: v_max_i32, v_max3_i32, v_dot4, every DPP form ...) or 8 cycles (tools/microbench/valu_rate*.hip).
+SIMDS = 256 * 4
+CLOCK_HZ = 2.4e9
+SIMD_CYCLES_PER_S = SIMDS * CLOCK_HZ       # the VALU issue peak: 2457.6 G SIMD-cycles/s
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 78.6 T full-rate 32-bit lane-ops/s (informational: achieved_algorithmic_tops)
 HBM_PEAK_GBS = 8000.0
 REFERENCE_PUBLISHED_ALIGN_PER_S = 1e6 / 4.4    # README.md:4 of the reference: simd4 ~4.4 s / 1M on one EPYC 7501 core
+CONFIG3_PAIRS_PER_GPU = 1 << 26                # BASELINE.json configs[3]: 512M pairs over 8 GPUs
+
+
+def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None):
+    """VALU issue-bound utilisation of one launch, derived from the shipped library's disassembly (tools/isa_census.py).
+
+    `trips` = iterations of the main loop AS WRITTEN IN THE SOURCE; `marker` = (mnemonic, count per source iteration):
+    hipcc unrolls some instantiations, and the number of marker instructions in the compiled loop body says by how much.
+    Returns the dict that goes into a `roofline` object: achieved / peak in G SIMD-issue-cycles per second and
+    frac = achieved / peak <= 1 by construction (a kernel cannot issue more VALU cycles than elapsed)."""
+    try:
+        import isa_census
+        found = isa_census.census_for(kernel_regex, marker_op=marker[0] if marker else None)
+        if len(found) != 1:
+            raise RuntimeError("%d kernels match %r" % (len(found), kernel_regex))
+        name, c = next(iter(found.items()))
+        if marker:
+            unroll = c["main_loop"]["by_op"].get(marker[0], 0) / float(marker[1])
+            if unroll < 1:
+                raise RuntimeError("main loop of %s holds %d %s, fewer than one source iteration's %d" % (
+                    name, c["main_loop"]["by_op"].get(marker[0], 0), marker[0], marker[1]))
+            trips = trips / unroll
+    except Exception as e:                  # no llvm-objdump on this box: say so, never invent a fraction
+        return {"frac": None, "census_error": repr(e)}
+    kernel_s = kernel_ms * 1e-3
+    cyc_ideal = isa_census.issue_cycles_per_wave(c, trips, "ideal")
+    cyc_meas = isa_census.issue_cycles_per_wave(c, trips, "measured")
+    achieved = waves * cyc_ideal / kernel_s
+    return {
+        "bound": "valu", "kernel": name, "kernel_code_sha256": c["code_sha256"],
+        "achieved": round(achieved / 1e9, 1), "peak": round(SIMD_CYCLES_PER_S / 1e9, 1), "unit": "G VALU issue cycles/s (sum over 1024 SIMDs)",
+        "frac": round(achieved / SIMD_CYCLES_PER_S, 4),
+        "frac_at_measured_instruction_rates": round(waves * cyc_meas / kernel_s / SIMD_CYCLES_PER_S, 4),
+        "census": {"source": "tools/isa_census.py on the libswmi.so being timed (class costs: profiles/r01_microbench_valu_rate*.txt)",
+                   "main_loop_trips": round(trips, 2), "wavefronts_per_launch": waves,
+                   "valu_instructions_per_wavefront": round(isa_census.valu_instructions_per_wave(c, trips)),
+                   "issue_cycles_per_wavefront": round(cyc_ideal, 1),
+                   "main_loop_valu_by_op": c["main_loop"]["by_op"],
+                   "main_loop_issue_cycles": c["main_loop"]["issue_cycles_ideal"],
+                   "unmeasured_valu_in_main_loop": c["main_loop"]["unmeasured_valu"]},
+    }
+
+
+def stamped_profile(kernel_code_sha256):
+    """PMC-derived figures (HBM traffic per launch, effective clock) from the committed profile, only if they were taken
+    on exactly the kernel code that is being timed now (profiles/traffic.json carries the code hash)."""
+    f = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tr = json.load(open(f))
+    except Exception:
+        return None, "profiles/traffic.json missing"
+    if tr.get("kernel_code_sha256") != kernel_code_sha256:
+        return None, "profiles/traffic.json was taken on kernel code %s, the library being timed carries %s: not quoted" % (
+            tr.get("kernel_code_sha256"), kernel_code_sha256)
+    return tr, tr.get("source")
+
+
+def effective_cores():
+    """Cores the container may actually use: the cgroup CPU quota (cpu.max), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return round(float(quota) / float(period), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return round(q / p, 2)
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count()
 
 
 def parse():
@@ -48,15 +141,17 @@ def parse():
     ap.add_argument("--gap-open", type=int, default=5)
     ap.add_argument("--gap-extend", type=int, default=1)
     ap.add_argument("--mode", default="pairs", choices=["pairs", "packed", "one-vs-many", "banded-affine", "semiglobal"],
-                    help="pairs = the headline path; packed = 2-bit inputs (SURVEY 8f N3); one-vs-many = every seq1 against "
-                         "ONE seq2 (N1) -- secondary rows, same kernel, same contract")
-    ap.add_argument("--pairs", type=int, default=1 << 20, help="pairs per GPU per step")
+                    help="pairs = the headline path (+ rows); the others run ONE secondary row as a line of its own "
+                         "(what tools/profile_rows.sh profiles)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (0 = 1,048,576 on one GPU, 67,108,864 per GPU on several)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per alignment (0 = library default)")
     ap.add_argument("--match", type=int, default=10)
     ap.add_argument("--mismatch", type=int, default=-30)
     ap.add_argument("--gap", type=int, default=15)
     ap.add_argument("--seed", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="N = 1: headline only (profiling passes use this)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5)
     ap.add_argument("--force-dist", action="store_true", help="create the process group and run the score gather even "
                     "with one rank (rehearses the RCCL path on a one-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
@@ -96,11 +191,12 @@ def cpu_baseline(swmi, np, args, gpu_scores_head, sample):
                 "repeat_one_pair_ms_per_1M": round(rep_ms, 1)}
         # the same simd4 on ALL host cores (SURVEY 8d iii): contiguous shards, one thread each (ctypes drops the GIL)
         from concurrent.futures import ThreadPoolExecutor
-        threads = os.cpu_count() or 1
+        cores = effective_cores()
+        threads = max(1, min(os.cpu_count() or 1, int(round(cores)) if cores else 1))
         bounds = [(sample * t // threads, sample * (t + 1) // threads) for t in range(threads)]
         out_mt = np.zeros(sample, np.int32)
 
-        passes = 16                                        # each thread scores its shard 16 times: ~0.5 s of work per thread
+        passes = 4                                         # each thread scores its shard 4 times
 
         def shard(b):
             lo, hi = b
@@ -111,10 +207,10 @@ def cpu_baseline(swmi, np, args, gpu_scores_head, sample):
             t2 = time.perf_counter()
             list(ex.map(shard, bounds))
             dt_mt = time.perf_counter() - t2
-        info["all_host_cores"] = {"threads": threads, "value": round(sample * passes / dt_mt, 1), "unit": "alignments/s",
+        info["all_host_cores"] = {"threads": threads, "effective_cores": cores, "logical_cpus_visible": os.cpu_count(),
+                                  "value": round(sample * passes / dt_mt, 1), "unit": "alignments/s",
                                   "agrees_with_one_core": bool((out_mt == out).all()),
-                                  "note": "threads = os.cpu_count(); a container CPU quota (16 cores per GPU on the test "
-                                          "boxes) caps what they deliver"}
+                                  "note": "threads = the container's CPU quota (cgroup cpu.max), not os.cpu_count()"}
     else:
         orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         t0 = time.perf_counter()
@@ -129,15 +225,48 @@ def cpu_baseline(swmi, np, args, gpu_scores_head, sample):
         model = "unknown"
     info.update({"value": round(sample / dt, 1), "unit": "alignments/s", "cores": 1,
                  "sample": "%d distinct generated pairs (seed %d, pairs 0..%d), same parameters" % (sample, args.seed, sample - 1),
-                 "seconds": round(dt, 2), "host_cpu": model, "host_cores_available": os.cpu_count(),
+                 "seconds": round(dt, 2), "host_cpu": model, "host_cores_available": effective_cores(),
                  "gpu_scores_checked": sample, "gpu_mismatches": mism})
     return info
 
 
-def bench_banded(args, swmi, np, torch, local_rank):
+def oracle_scores(np, seq1, seq2, sm, gap):
+    """CPU checker for a sample: the reference's simd4 when oracle/_ref is present, else the C oracle (OpenMP)."""
+    vp = ctypes.c_void_p
+    n = seq1.shape[0]
+    out = np.zeros(n, np.int32)
+    a, b = np.ascontiguousarray(seq1), np.ascontiguousarray(seq2)
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
+    in_simd4_domain = int(np.min(sm)) >= -127 and gap >= 0
+    if os.path.exists(ref_path) and in_simd4_domain:
+        ctypes.CDLL(ref_path).swref_batch(4, a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.c_size_t(n),
+                                          sm.ctypes.data_as(vp), int(gap), out.ctypes.data_as(vp))
+        return out, "reference simd4 (oracle/_ref)"
+    ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")).sw_oracle_batch(
+        a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.c_size_t(n), sm.ctypes.data_as(vp), int(gap), out.ctypes.data_as(vp))
+    return out, "oracle/sw_oracle.c"
+
+
+def time_launches(torch, stream, launch, steps, warmup):
+    """Average per-launch duration (ms) of `steps` back-to-back launches, HIP events on the launch stream."""
+    for _ in range(warmup):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(steps):
+        launch()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def bench_banded(args, swmi, np, torch, local_rank, steps=None, warmup=None):
     """Secondary row: 1024 x 1024 affine gap, 128-diagonal band, one wavefront per alignment (single GPU)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     length = args.len
-    P = args.pairs if args.pairs != (1 << 20) else 1 << 16
+    P = args.pairs if args.pairs and args.mode == "banded-affine" else 1 << 16
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream()
     npairs128 = P * length // 128               # reuse the 128-mer generator: P len-mers = P*len/128 consecutive 128-mers
@@ -153,30 +282,33 @@ def bench_banded(args, swmi, np, torch, local_rank):
     def launch():
         swmi.score_banded_affine_device(d1.data_ptr(), d2.data_ptr(), P, length, sm, args.gap_open, args.gap_extend,
                                         scores.data_ptr(), stream.cuda_stream)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         launch()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in ev:
         a.record(stream); launch(); b.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     band_cells = sum(min(length, i + 63) - max(1, i - 64) + 1 for i in range(1, length + 1))
-    value = P * args.steps / elapsed
+    value = P * steps / elapsed
+    # one wavefront per alignment; main loop = `length` iterations of two anti-diagonal steps (sw_banded_affine_kernel)
+    roof = issue_bound(r"^sw_banded_affine_kernel<%d>$" % (1 if args.gap_open >= args.gap_extend else 0), length, P, kernel_ms,
+                       marker=("v_dot4_i32_i8", 2))
+    # 12 algorithmic int ops per cell: 4 sub, 2+3 max, 1 add, 1 running max, 1 lookup (informational)
+    roof.update({"kernel_ms": round(kernel_ms, 4), "traffic": None,
+                 "achieved_algorithmic_tops": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12, 3),
+                 "gcups_kernel": round(P * band_cells / (kernel_ms * 1e-3) / 1e9, 1)})
     line = {"metric": "alignments/sec (and GCUPS), banded affine extension", "value": round(value, 1), "unit": "alignments/s",
-            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "gcups": round(value * band_cells / 1e9, 1),
             "config": {"workload": "BASELINE.json configs[4] (extension, parity unpinned by the reference): %d pairs of %d-mers, "
                                    "128-diagonal band, sm 2/-3, gap open %d extend %d, inputs resident in HBM" % (
                                        P, length, args.gap_open, args.gap_extend), "band_cells_per_alignment": band_cells},
-            "roofline": {"bound": "valu", "kernel": "sw_banded_affine_kernel", "kernel_ms": round(kernel_ms, 4),
-                         # 12 algorithmic int ops per cell: 4 sub, 2+3 max, 1 add, 1 running max, 1 lookup
-                         "achieved": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12, 3), "peak": round(VALU_PEAK_TOPS, 1),
-                         "unit": "TOP/s (int32)", "frac": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
-                         "traffic": None},
+            "roofline": roof,
             "checksum": int(scores.to(torch.int64).sum().item())}
     if not args.no_cpu_baseline:
         sample = 256
@@ -189,41 +321,36 @@ def bench_banded(args, swmi, np, torch, local_rank):
         want = np.array([orc.sw_oracle_banded_affine(a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), length,
                                                      sm.ctypes.data_as(vp), args.gap_open, args.gap_extend) for k in range(sample)], np.int32)
         dt = time.perf_counter() - t0
-        line["cpu_baseline"] = {"kind": "port", "function": "oracle/sw_oracle.c sw_oracle_banded_affine (scalar, full tables)",
+        line["cpu_baseline"] = {"kind": "port", "function": "oracle/sw_oracle.c sw_oracle_banded_affine (scalar, full tables); parity unpinned by the reference",
                                 "value": round(sample / dt, 1), "unit": "alignments/s", "cores": 1,
                                 "sample": "first %d pairs of the batch" % sample,
                                 "gpu_mismatches": int((want != scores[:sample].cpu().numpy()).sum())}
-    print(json.dumps(line), flush=True)
-    return 0
+    return line
 
 
-def sg_sweep_kernel(P):
-    """Name of the sweep kernel launch_semiglobal picks for P alignments (same cost model as sg_kernels.hip)."""
-    if P < 6144:
-        return "sg_forward_kernel<8>"
-    w4, w2 = (P // 16 + 1023) // 1024, (P // 32 + 1023) // 1024
-    t4 = 16.2 if w4 <= 1 else 23.5 if w4 == 2 else 31.7 if w4 == 3 else 5.7 + 8.57 * w4
-    t2 = 38.0 if w2 <= 2 else 6.6 + 15.45 * w2
-    return "sg_forward_split_kernel<4, %d>" % min(max(w4, 1), 4) if t4 <= t2 else "sg_forward_split_kernel<2, %d>" % (2 if w2 <= 2 else 3)
+def sg_traffic(P, kernel, code_sha):
+    """HBM bytes per launch of the sweep kernel from the committed PMC passes (65536 alignments), or None; quoted only
+    when the profile was taken on the same kernel code."""
+    for name in ("r02_semiglobal_pmc.json", "r01_semiglobal_pmc.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if P != 65536 or not os.path.exists(f):
+            continue
+        try:
+            doc = json.load(open(f))
+            k = doc.get(kernel, {})
+            if doc.get("kernel_code_sha256", {}).get(kernel) != code_sha:
+                continue
+            return int(k["hbm_read_bytes_x2"] + k["hbm_write_bytes"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
-def sg_traffic(P, kernel):
-    """HBM bytes per launch of the sweep kernel from the committed PMC passes (65536 alignments), or None."""
-    f = os.path.join(ROOT, "profiles", "r01_semiglobal_pmc.json")
-    if P != 65536 or not os.path.exists(f):
-        return None
-    try:
-        k = json.load(open(f)).get(kernel, {})
-        return int(k["hbm_read_bytes_x2"] + k["hbm_write_bytes"])
-    except Exception:
-        return None
-
-
-def bench_semiglobal(args, swmi, np, torch, local_rank):
+def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None):
     """Secondary row: the reference's semi-global adaptive-band X-drop aligner incl. traceback (single GPU).
     Inputs follow SpeedtestSemiGlobal (source.cpp:2805-2813): a random 16384-mer and a copy with 5 % substitutions."""
     L = 16384
-    P = args.pairs if args.pairs != (1 << 20) else 65536
+    P = args.pairs if args.pairs and args.mode == "semiglobal" else 65536
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream()
     g = torch.Generator(device=dev); g.manual_seed(args.seed)
@@ -231,6 +358,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     rnd = torch.randint(0, 4, (P, L), dtype=torch.uint8, device=dev, generator=g)
     keep = torch.rand((P, L), device=dev, generator=g) < 0.95
     d2 = torch.where(keep, d1, rnd).contiguous()
+    del rnd, keep
     cap = 32769
     scores = torch.empty(P, dtype=torch.int32, device=dev)
     lengths = torch.empty(P, dtype=torch.int32, device=dev)
@@ -239,7 +367,8 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     def launch():
         swmi.semiglobal_xdrop_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(),
                                      stream.cuda_stream)
-    steps, warm = min(args.steps, 10), min(args.warmup, 2)
+    steps = min(args.steps, 10) if steps is None else steps
+    warm = min(args.warmup, 2) if warmup is None else warmup
     for _ in range(warm):
         launch()
     torch.cuda.synchronize()
@@ -267,22 +396,23 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
     rounds, ops_cell = 32768, 9
     sweep_ops = P * rounds * 32 * ops_cell
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
-    sweep_kernel = sg_sweep_kernel(P)
-    line["roofline"] = {
-        "bound": "valu", "kernel": sweep_kernel,
-        "kernel_ms": round(sweep_ms, 3), "achieved": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),
-        "peak": round(VALU_PEAK_TOPS, 1), "unit": "TOP/s (int32)",
-        "frac": round(sweep_ops / (sweep_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4),
+    sweep_kernel, tb_kernel = swmi.semiglobal_kernels_for_batch(P)          # the library says which mapping it ran
+    name = sweep_kernel.replace(" ", "")
+    # wavefronts of the sweep: 32 / 16 alignments per wavefront with the band over 2 / 4 lanes, 2 with a band per half-wavefront
+    per_wave = {"sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(name.split(",")[0], 2)
+    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms)
+    traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
+    roof.update({
+        "kernel_ms": round(sweep_ms, 3), "traceback_kernels": tb_kernel, "traceback_kernel_ms": round(tb_ms, 3),
+        "achieved_algorithmic_tops": round(sweep_ops / (sweep_ms * 1e-3) / 1e12, 3),
         "algorithmic_ops_per_launch": sweep_ops, "gcups_kernel": round(P * rounds * 32 / (sweep_ms * 1e-3) / 1e9, 1),
-        "traffic": sg_traffic(P, sweep_kernel),
-        "traffic_source": "profiles/r01_semiglobal_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the sweep kernel, separate passes; "
-                          "the records leave in 64-byte pieces of 128-byte L2 lines, hence the read-for-ownership traffic)",
+        "traffic": traffic, "traffic_source": traffic_src,
         "kernel_ms_covers": "sweep phase between HIP events: the stream-packing pre-pass (~0.6 ms at 65536) + the sweep kernel",
-        "traceback_kernel_ms": round(tb_ms, 3),
         "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / ((sweep_ms + tb_ms) * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / ((sweep_ms + tb_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "sequences in + (i, j) pairs out; the predecessor records between the two kernels (10 B per round, "
-                        "written once and read once) are implementation traffic on top"}}
+                "note": "sequences in + (i, j) pairs out; the predecessor records between the two kernels are implementation "
+                        "traffic on top"}})
+    line["roofline"] = roof
     if not args.no_cpu_baseline:
         ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
         sample = 64
@@ -307,9 +437,362 @@ def bench_semiglobal(args, swmi, np, torch, local_rank):
             line["cpu_baseline"] = {"kind": "reference", "function": "SemiGlobal_AdaptiveBanded_XDrop_111_32_70_simd_mark4 (source.cpp:2543), g++ -O3 -mavx2",
                                     "value": round(res["simd_mark4"], 1), "unit": "alignments/s", "cores": 1,
                                     "simd_variant_alignments_per_s": round(res["simd"], 1),
-                                    "sample": "first %d pairs of the batch" % sample, "gpu_mismatches": mism}
-    print(json.dumps(line), flush=True)
-    return 0
+                                    "sample": "first %d pairs of the batch (score + whole traceback compared)" % sample, "gpu_mismatches": mism}
+        else:
+            orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+            t0 = time.perf_counter()
+            for k in range(8):
+                sc, ln, oob = ctypes.c_int32(), ctypes.c_size_t(), ctypes.c_int()
+                orc.sg_oracle_xdrop(a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), ctypes.byref(sc), tbh.ctypes.data_as(vp),
+                                    ctypes.c_size_t(40000), ctypes.byref(ln), ctypes.byref(oob))
+                ok = sc.value == got_scores[k] and ln.value == got_len[k] and np.array_equal(tbh[: ln.value], got_tb[k, : ln.value])
+                mism += 0 if ok else 1
+            line["cpu_baseline"] = {"kind": "port", "function": "oracle/sg_oracle.c", "value": round(8 / (time.perf_counter() - t0), 1),
+                                    "unit": "alignments/s", "cores": 1, "sample": "first 8 pairs of the batch", "gpu_mismatches": mism}
+    return line
+
+
+def row_summary(line):
+    """The part of a secondary line that goes into the headline's `rows` object."""
+    r = line["roofline"]
+    out = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+           "kernel": r.get("kernel"), "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"),
+           "frac_at_measured_instruction_rates": r.get("frac_at_measured_instruction_rates"),
+           "gcups_kernel": r.get("gcups_kernel"), "workload": line["config"]["workload"]}
+    for k in ("traceback_kernel_ms", "traffic"):
+        if r.get(k) is not None:
+            out[k] = r[k]
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["gpu_mismatches"] = cb["gpu_mismatches"]
+        out["checked_against"] = "%s, %s" % (cb["function"], cb["sample"])
+        out["cpu_one_core"] = cb["value"]
+    return out
+
+
+def sw128_roofline(swmi, P, lanes, flags, mode, kernel_ms, match, mismatch, gap):
+    """`roofline` object of one sw128_kernel launch over P pairs."""
+    sm_gap_fits = all(-128 <= v + gap <= 127 for v in (match, mismatch))
+    fold = 1 if (sm_gap_fits and not (flags & 1)) else 0
+    mode_id = {"pairs": 0, "packed": 1, "one-vs-many": 2}[mode]
+    trips = (128 + lanes) // 2                   # T2 of sw128_kernel: pairs of anti-diagonal steps
+    waves = (P + 64 // lanes - 1) // (64 // lanes)
+    kernel_s = kernel_ms * 1e-3
+    roof = issue_bound(r"^sw128_kernel<%d,%d,%d,%d>$" % (lanes, fold, 1 if flags & 2 else 0, mode_id), trips, waves, kernel_ms,
+                       marker=("v_dot4_i32_i8", 2 * (128 // lanes)))     # one v_dot4 per cell, 2 steps x R cells per source iteration
+    bytes_per_alignment = {"pairs": BYTES_PER_ALIGNMENT, "packed": 32 + 32 + 4, "one-vs-many": 128 + 4}[mode]
+    roof.update({
+        "kernel_ms": round(kernel_ms, 4), "traffic": None,
+        "achieved_algorithmic_tops": round(P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12, 3),
+        "algorithmic_note": "7 int ops per cell (SURVEY 8d) against the 78.6 T full-rate lane-op/s peak would read %.2f: fused "
+                            "instructions (v_dot4 = lookup + add, v_max3 = two max) retire several algorithmic ops per issue "
+                            "slot, so that ratio is not a utilisation; `frac` is" % (P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12 / VALU_PEAK_TOPS),
+        "algorithmic_ops_per_launch": P * INT_OPS_PER_ALIGNMENT,
+        "algorithmic_bytes_per_launch": P * bytes_per_alignment,
+        "hbm": {"achieved": round(P * bytes_per_alignment / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(P * bytes_per_alignment / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
+        "gcups_kernel": round(P * CELLS / kernel_s / 1e9, 1)})
+    return roof
+
+
+def single_gpu(args, swmi, np, torch, local_rank):
+    """N = 1: the headline (configs[1]) + rows + sustained."""
+    P = args.pairs or (1 << 20)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    if args.lanes:
+        swmi.set_schedule(args.lanes, 0)
+    lanes, flags = swmi.get_schedule()
+    lanes = lanes or swmi.schedule_for_batch(P)
+    d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+    d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+    scores = torch.empty(P, dtype=torch.int32, device=dev)
+    swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, 0, stream.cuda_stream)
+    sm = swmi.match_matrix(args.match, args.mismatch)
+    p1 = p2 = None
+    if args.mode == "packed":                   # pack on the device with torch (input preparation, outside the timed region)
+        def pack(d):
+            v = d.view(P, 32, 4).to(torch.int32)
+            return (v[..., 0] | (v[..., 1] << 2) | (v[..., 2] << 4) | (v[..., 3] << 6)).to(torch.uint8).contiguous()
+        p1, p2 = pack(d1), pack(d2)
+
+    def launch(mode=None, out=None):
+        mode = mode or args.mode
+        out_ptr = (out if out is not None else scores).data_ptr()
+        if mode == "packed":
+            swmi.score_batch_device(p1.data_ptr(), p2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream, packed=True)
+        elif mode == "one-vs-many":
+            swmi.score_one_vs_many_device(d1.data_ptr(), P, d2.data_ptr(), sm, args.gap, out_ptr, stream.cuda_stream)
+        else:
+            swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream)
+
+    # settle the clocks first: after idle the first ~10 launches run 10 % slower (DVFS ramp); extra untimed work on top of
+    # the W warmup steps the caller asked for, so that a small W still measures the steady state
+    for _ in range(40 + args.warmup):
+        launch()
+    # HIP events bracket every `stride`-th launch of the timed region: an event pair per launch costs ~20 us of stream time
+    # (1.3 % of a 1.5 ms step), which would show up in `value`
+    stride = max(1, int(os.environ.get("SWMI_BENCH_EVENT_STRIDE", "8")))
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % stride == 0 else None
+              for k in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if events[k]:
+            events[k][0].record(stream)
+        launch()
+        if events[k]:
+            events[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed = [ev for ev in events if ev is not None]
+    kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)      # HIP events on the launch stream
+    value = P * args.steps / elapsed
+    roof = sw128_roofline(swmi, P, lanes, flags, args.mode, kernel_ms, args.match, args.mismatch, args.gap)
+    prof, prof_src = stamped_profile(roof.get("kernel_code_sha256"))
+    if prof and prof.get("pairs_per_launch") == P and args.mode == "pairs":
+        roof["traffic"] = prof.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = prof_src
+        if prof.get("effective_clock_ghz"):
+            roof["effective_clock_ghz"] = prof["effective_clock_ghz"]
+            roof["effective_clock_source"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same profile (profiled passes clock a little lower than un-profiled ones)"
+            if roof.get("frac") is not None:
+                roof["frac_at_effective_clock"] = round(roof["frac"] * CLOCK_HZ / (prof["effective_clock_ghz"] * 1e9), 4)
+    else:
+        roof["traffic_note"] = prof_src
+    checksum = int(scores.to(torch.int64).sum().item())
+    line = {
+        "metric": "alignments/sec (and GCUPS) on 1M fixed-length pairs, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "alignments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": round(value / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
+        "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
+        "dtype": "int32", "data": "synthetic",
+        "gcups": round(value * CELLS / 1e9, 1),
+        "config": {"workload": "%s: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, inputs resident in HBM, int32 scores" % (
+                       {"pairs": "BASELINE.json configs[1]", "packed": "SURVEY 8f N3 (2-bit packed inputs, source.cpp:1581)",
+                        "one-vs-many": "SURVEY 8f N1 (every seq1 vs ONE seq2, source.cpp:1227)"}[args.mode],
+                       P, args.match, args.mismatch, args.gap),
+                   "pairs_per_gpu": P, "global_pairs": P, "lanes_per_alignment": lanes, "schedule_flags": flags,
+                   "parallelism": "batch-sharded x1"},
+        "roofline": roof, "checksum": checksum,
+    }
+    if args.mode != "pairs":
+        a_h, b_h = swmi.generate_pairs_host(4096, args.seed, 0)
+        if args.mode == "one-vs-many":
+            b_h = np.repeat(b_h[:1], 4096, axis=0)
+        want, who = oracle_scores(np, a_h, b_h, sm, args.gap)
+        line["cpu_baseline"] = {"kind": "reference" if "reference" in who else "port", "function": who, "sample": "first 4096 pairs",
+                                "gpu_mismatches": int((want != scores[:4096].cpu().numpy()).sum()), "value": None, "unit": "alignments/s", "cores": 1}
+        return line
+    head_scores = scores.cpu().numpy()
+    if not args.no_cpu_baseline:
+        sample = args.cpu_sample or min(P, 1 << 20)
+        line["cpu_baseline"] = cpu_baseline(swmi, np, args, head_scores, min(sample, P))
+        line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)
+        # end-to-end through the host-buffer entry point (H2D + kernel + D2H; SURVEY 8d "reported separately"; never `value`)
+        h1, h2 = swmi.generate_pairs_host(P, args.seed, 0)
+        swmi.score_batch(h1, h2, sm, args.gap)
+        t3 = time.perf_counter()
+        hs = swmi.score_batch(h1, h2, sm, args.gap)
+        dt3 = time.perf_counter() - t3
+        line["host_buffer_path"] = {"entry": "swmi_score_batch (pageable host memory, PCIe inclusive)",
+                                    "ms": round(dt3 * 1e3, 3), "value": round(P / dt3, 1), "unit": "alignments/s",
+                                    "matches_resident_scores": bool((hs == head_scores).all())}
+        del h1, h2
+    if args.no_rows:
+        return line
+
+    # ---- sustained: >= 2 s of back-to-back launches of the headline kernel (so that a sampling monitor sees the GPU busy)
+    n_sus = max(args.steps, int(args.sustained_seconds / (kernel_ms * 1e-3)) + 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_sus):
+        launch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    line["sustained"] = {"launches": n_sus, "seconds": round(dt, 3), "value": round(P * n_sus / dt, 1), "unit": "alignments/s",
+                         "ms_per_step": round(dt * 1e3 / n_sus, 4),
+                         "checksum_unchanged": int(scores.to(torch.int64).sum().item()) == checksum}
+
+    # ---- rows: the other rows of SURVEY.md section 8, short runs, same contract --------------------------------------
+    rows = {}
+    out2 = torch.empty(P, dtype=torch.int32, device=dev)
+    a_h, b_h = swmi.generate_pairs_host(4096, args.seed, 0)
+
+    def sw_row(name, mode, lanes_row, workload):
+        swmi.set_schedule(lanes_row, 0)
+        try:
+            ms = time_launches(torch, stream, lambda: launch(mode, out2), 20, 5)
+        finally:
+            swmi.set_schedule(args.lanes, 0)
+        got = out2.cpu().numpy()
+        r = sw128_roofline(swmi, P, lanes_row or swmi.schedule_for_batch(P), 0, mode, ms, args.match, args.mismatch, args.gap)
+        row = {"value": round(P / (ms * 1e-3), 1), "unit": "alignments/s", "kernel": r.get("kernel"), "kernel_ms": r["kernel_ms"],
+               "frac": r.get("frac"), "frac_at_measured_instruction_rates": r.get("frac_at_measured_instruction_rates"),
+               "gcups_kernel": r["gcups_kernel"], "steps": 20, "workload": workload}
+        if mode == "one-vs-many":
+            want, who = oracle_scores(np, a_h, np.repeat(b_h[:1], 4096, axis=0), sm, args.gap)
+            row["gpu_mismatches"] = int((want != got[:4096]).sum())
+            row["checked_against"] = "%s, first 4096 sequences" % who
+        else:                                   # same pairs as the headline, whose 1M scores the reference's simd4 has just checked
+            row["gpu_mismatches"] = int((got != head_scores).sum())
+            row["checked_against"] = "all %d scores of the headline batch (themselves compared with the reference's simd4 above)" % P
+        rows[name] = row
+
+    sw_row("one_wavefront_per_alignment_L64", "pairs", 64,
+           "configs[1] pairs with north_star's literal mapping: one 64-lane wavefront per alignment (swmi_set_schedule(64))")
+    def pack(d):
+        v = d.view(P, 32, 4).to(torch.int32)
+        return (v[..., 0] | (v[..., 1] << 2) | (v[..., 2] << 4) | (v[..., 3] << 6)).to(torch.uint8).contiguous()
+    p1, p2 = pack(d1), pack(d2)
+    sw_row("packed_2bit_input", "packed", 0, "SURVEY 8f N3: the same pairs in the reference's 2-bit wire format (source.cpp:1581), 68 B per pair")
+    sw_row("one_vs_many", "one-vs-many", 0, "SURVEY 8f N1: every seq1 against ONE seq2 (source.cpp:1227)")
+    del p1, p2, out2
+    # N2 (fixed (1,-1,1) scorer, source.cpp:1073-1225): the general kernel with those parameters
+    sm111 = swmi.match_matrix(1, -1)
+    ms111 = time_launches(torch, stream, lambda: swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm111, 1, scores.data_ptr(),
+                                                                         stream.cuda_stream), 20, 5)
+    want111, who = oracle_scores(np, a_h, b_h, sm111, 1)
+    r111 = sw128_roofline(swmi, P, lanes, flags, "pairs", ms111, 1, -1, 1)
+    rows["fixed_111_scorer"] = {"value": round(P / (ms111 * 1e-3), 1), "unit": "alignments/s", "kernel": r111.get("kernel"),
+                                "kernel_ms": r111["kernel_ms"], "frac": r111.get("frac"), "steps": 20,
+                                "gpu_mismatches": int((want111 != scores[:4096].cpu().numpy()).sum()), "checked_against": "%s, first 4096 pairs" % who,
+                                "workload": "SURVEY 8f N2: sm +1/-1, gap 1 (SmithWaterman_8bit111simd, source.cpp:1105-1225) on the general kernel"}
+    del d1, d2, scores
+    torch.cuda.empty_cache()
+    rows["banded_affine_1024"] = row_summary(bench_banded(args, swmi, np, torch, local_rank, steps=10, warmup=3))
+    torch.cuda.empty_cache()
+    rows["semiglobal_xdrop_65536"] = row_summary(bench_semiglobal(args, swmi, np, torch, local_rank, steps=3, warmup=1))
+    line["rows"] = rows
+    return line
+
+
+def multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank):
+    """N > 1 (or --force-dist): contiguous shards, scores all-gathered through swmi/sharding.py."""
+    from swmi import sharding
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    if args.lanes:
+        swmi.set_schedule(args.lanes, 0)
+    sm = swmi.match_matrix(args.match, args.mismatch)
+    alloc = lambda n: torch.empty(n, dtype=torch.int32, device=dev)        # noqa: E731
+
+    def run_leg(P, mode, steps, warmup, keep=False):
+        """One timed leg: `steps` passes over this rank's P resident pairs; returns the per-leg record (and tensors if keep)."""
+        n_total = P * world
+        lo, hi = sharding.shard_bounds(n_total, rank, world)
+        d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+        d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
+        swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
+        pipe = sharding.GatherPipeline(n_total, rank, world, alloc, None, mode, depth=4 if P <= (1 << 22) else 2)
+
+        def launch(out):
+            swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, out.data_ptr(), stream.cuda_stream)
+        for k in range(warmup):
+            pipe.step(k, launch)
+        pipe.finish()
+        torch.cuda.synchronize()
+        stride = 1 if P > (1 << 22) else 8
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % stride == 0 else None
+                  for k in range(steps)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev = events[k]
+            pipe.step(k, launch, (lambda e=ev: e[0].record(stream)) if ev else None, (lambda e=ev: e[1].record(stream)) if ev else None)
+        full = pipe.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        timed = [ev for ev in events if ev is not None]
+        kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
+        # exposed cost of one gather with nothing to hide behind (kernel done, stream idle): host-timed around a synchronous one
+        gather_ms = 0.0
+        if mode != "none":
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            sharding.gather_scores(pipe.local[pipe.last_slot], n_total, None, out=pipe.full[0])
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+        per_rank = torch.tensor([kernel_ms, gather_ms], dtype=torch.float64, device=dev)
+        every = torch.empty(2 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, per_rank)
+        every = every.cpu().numpy().reshape(world, 2)
+        rec = {"pairs_per_gpu": P, "global_pairs": n_total, "steps": steps, "gather": {"every": "after every step (async, overlapped)",
+               "final": "one, after the last step", "none": "none (scores stay sharded)"}[mode],
+               "value": round(n_total * steps / elapsed, 1), "unit": "alignments/s", "ms_per_step": round(elapsed * 1e3 / steps, 4),
+               "kernel_ms_per_rank": [round(float(x), 4) for x in every[:, 0]],
+               "isolated_gather_ms_per_rank": [round(float(x), 3) for x in every[:, 1]],
+               "gather_bytes_per_rank": 4 * P if mode != "none" else 0}
+        if keep:
+            return rec, full, kernel_ms, n_total
+        del d1, d2, pipe, full
+        torch.cuda.empty_cache()
+        return rec
+
+    P = args.pairs or CONFIG3_PAIRS_PER_GPU
+    small = min(P, 1 << 20)
+    for _ in range(2):                          # settle clocks and the communicator on the small shape first
+        run_leg(small, "every", 20, 10)
+    legs = {}
+    legs["configs1_size_gather_every_step"] = run_leg(small, "every", max(args.steps, 50), args.warmup)
+    legs["no_gather"] = run_leg(P, "none", args.steps, min(args.warmup, 3))
+    legs["one_final_gather"] = run_leg(P, "final", args.steps, min(args.warmup, 3))
+    head, full, kernel_ms, n_total = run_leg(P, "every", args.steps, min(args.warmup, 3), keep=True)
+    legs["gather_every_step"] = head
+
+    # every rank must hold the same, complete score vector after the gather
+    checksum = int(full.to(torch.int64).sum().item())
+    c = torch.tensor([checksum], dtype=torch.int64, device=dev)
+    cmin, cmax = c.clone(), c.clone()
+    dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    ranks_agree = int(cmin.item()) == int(cmax.item())
+    line = None
+    if rank == 0:
+        # a sample of EVERY shard of the gathered vector against the CPU checker: head, middle and tail of each shard
+        per = 1024
+        checked = mism = 0
+        who = ""
+        for r in range(world):
+            lo, hi = sharding.shard_bounds(n_total, r, world)
+            for first in sorted({lo, max(lo, (lo + hi) // 2 - per // 2), max(lo, hi - per)}):
+                m = min(per, hi - first)
+                a_h, b_h = swmi.generate_pairs_host(m, args.seed, first)
+                want, who = oracle_scores(np, a_h, b_h, sm, args.gap)
+                mism += int((want != full[first:first + m].cpu().numpy()).sum())
+                checked += m
+        lanes, flags = swmi.get_schedule()
+        lanes = lanes or swmi.schedule_for_batch(P)
+        roof = sw128_roofline(swmi, P, lanes, flags, "pairs", kernel_ms, args.match, args.mismatch, args.gap)
+        roof["kernel_ms_note"] = "rank 0's kernel; every rank's is in legs.*.kernel_ms_per_rank"
+        line = {
+            "metric": "alignments/sec (and GCUPS) on 1M fixed-length pairs, 1/2/4/8 MI355X",
+            "value": head["value"], "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(head["value"] / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
+            "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
+            "dtype": "int32", "data": "synthetic", "gcups": round(head["value"] * CELLS / 1e9, 1),
+            "config": {"workload": "BASELINE.json configs[3] shape: %d random 128x128 pairs per GPU per step (%d in all), sm %d/%d gap %d, "
+                                   "inputs resident in HBM (generated on each GPU from the global pair index), int32 scores, RCCL "
+                                   "all-gather of the scores after every step, overlapped with the next step's kernel" % (
+                                       P, n_total, args.match, args.mismatch, args.gap),
+                       "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
+                       "parallelism": "batch-sharded x%d, one process per GPU, torch.distributed %s" % (world, args.backend),
+                       "n1_note": "N = 1 runs configs[1] (1M pairs per step, no gather); legs.configs1_size_gather_every_step is that "
+                                  "size on every GPU WITH the per-step gather"},
+            "legs": legs, "roofline": roof, "checksum": checksum, "ranks_agree_on_gathered_scores": ranks_agree,
+            "gpu_scores_checked": checked, "gpu_mismatches": mism,
+            "checked_against": "%s on head / middle / tail samples of every one of the %d shards of the gathered vector" % (who, world),
+        }
+    dist.barrier()
+    return line
 
 
 def main():
@@ -324,7 +807,6 @@ def main():
     import torch
     import torch.distributed as dist
     import swmi
-    from swmi import sharding
 
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
@@ -334,14 +816,11 @@ def main():
     local_rank %= n_dev                         # only differs from LOCAL_RANK in a gloo rehearsal on a smaller box
     torch.cuda.set_device(local_rank)
     swmi.init(local_rank)                       # raises if there is no gfx950 device: the bench never falls back
-    if args.lanes:
-        swmi.set_schedule(args.lanes, 0)
-    lanes, flags = swmi.get_schedule()
-    lanes = lanes or swmi.schedule_for_batch(args.pairs)      # 0 = automatic: what it resolves to for this batch size
-    if world > 1 or args.force_dist:
+    collective = world > 1 or args.force_dist
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # the gather's kernels run beside a scoring kernel that always has 16 384 workgroups queued: give their stream the
-        # dispatcher's preference so that they take the free wavefront slots as soon as they are ready
+        # the gather's kernels run beside a scoring kernel that always has thousands of workgroups queued: give their
+        # stream the dispatcher's preference so that they take the free wavefront slots as soon as they are ready
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -366,164 +845,14 @@ def main():
             os.close(saved_stdout)
 
     if args.mode == "banded-affine":            # BASELINE configs[4] (extension, parity unpinned by the reference)
-        return bench_banded(args, swmi, np, torch, local_rank)
-    if args.mode == "semiglobal":
-        return bench_semiglobal(args, swmi, np, torch, local_rank)
-    P = args.pairs
-    n_total = P * world
-    collective = world > 1 or args.force_dist   # the score gather (and the barriers) run whenever a process group exists
-    lo, hi = sharding.shard_bounds(n_total, rank, world)        # contiguous shard of the global pair index space
-    dev = torch.device("cuda", local_rank)
-    d1 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
-    d2 = torch.empty(P * 128, dtype=torch.uint8, device=dev)
-    p1 = p2 = None
-    # a ring of score buffers: the RCCL gather of step k (async, on the process group's stream) overlaps the kernels of the
-    # following steps; four deep, so that a gather that gets its compute units late does not hold up the next launch
-    nbuf = 4 if collective else 1
-    scores = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    gathered = [torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(nbuf)] if collective else scores
-    pending = [None] * nbuf
-    stream = torch.cuda.current_stream()
-    swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), P, args.seed, lo, stream.cuda_stream)
-    sm = swmi.match_matrix(args.match, args.mismatch)
-    if args.mode == "packed":                   # pack on the device with torch (input preparation, outside the timed region)
-        def pack(d):
-            v = d.view(P, 32, 4).to(torch.int32)
-            return (v[..., 0] | (v[..., 1] << 2) | (v[..., 2] << 4) | (v[..., 3] << 6)).to(torch.uint8).contiguous()
-        p1, p2 = pack(d1), pack(d2)
-
-    def launch(out_ptr):
-        if args.mode == "packed":
-            swmi.score_batch_device(p1.data_ptr(), p2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream, packed=True)
-        elif args.mode == "one-vs-many":
-            swmi.score_one_vs_many_device(d1.data_ptr(), P, d2.data_ptr(), sm, args.gap, out_ptr, stream.cuda_stream)
-        else:
-            swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm, args.gap, out_ptr, stream.cuda_stream)
-
-    def step(k, ev=None):
-        buf = k % len(scores)
-        if pending[buf] is not None:
-            pending[buf].wait()                 # stream-side wait: the gather that read scores[buf] nbuf steps ago is done
-        if ev is not None:
-            ev[0].record(stream)
-        launch(scores[buf].data_ptr())
-        if ev is not None:
-            ev[1].record(stream)
-        if collective:
-            pending[buf] = dist.all_gather_into_tensor(gathered[buf], scores[buf], async_op=True)
-
-    def drain():
-        for w in pending:
-            if w is not None:
-                w.wait()
-        torch.cuda.synchronize()
-
-    # settle the clocks first: after idle the first ~10 launches run 10 % slower (DVFS ramp, profiles/r01c kernel trace);
-    # this is extra untimed work on top of the W warmup steps the caller asked for, so that a small W still measures
-    # the steady state
-    for k in range(40):
-        step(k)
-    drain()
-    for k in range(args.warmup):
-        step(k)
-    drain()
-    # HIP events bracket every `stride`-th launch of the timed region: an event pair per launch costs ~20 us of stream time
-    # (1.3 % of a 1.5 ms step), which would show up in `value`
-    stride = max(1, int(os.environ.get("SWMI_BENCH_EVENT_STRIDE", "8")))
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % stride == 0 else None
-              for k in range(args.steps)]
-    if collective:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, events[k])
-    drain()
-    if collective:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if collective:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    timed = [ev for ev in events if ev is not None]
-    kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)      # HIP events on the launch stream
-
-    # every rank must hold the same, complete score vector after the gather
-    last = (args.steps - 1) % len(scores)
-    checksum = int(gathered[last].to(torch.int64).sum().item())
-    if collective:
-        c = torch.tensor([checksum], dtype=torch.int64, device=dev)
-        cmin, cmax = c.clone(), c.clone()
-        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
-        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
-        assert int(cmin.item()) == int(cmax.item()), "ranks disagree on the gathered scores"
-
-    if rank == 0:
-        value = n_total * args.steps / elapsed
-        kernel_s = kernel_ms * 1e-3
-        bytes_per_alignment = {"pairs": BYTES_PER_ALIGNMENT, "packed": 32 + 32 + 4, "one-vs-many": 128 + 4}[args.mode]
-        roof = {
-            "bound": "valu",
-            "kernel": "sw128_kernel<L=%d>" % lanes,
-            "achieved": round(P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12, 3),
-            "peak": round(VALU_PEAK_TOPS, 1),
-            "unit": "TOP/s (int32)",
-            "frac": round(P * INT_OPS_PER_ALIGNMENT / kernel_s / 1e12 / VALU_PEAK_TOPS, 4),
-            "traffic": None,
-            "kernel_ms": round(kernel_ms, 4),
-            "algorithmic_ops_per_launch": P * INT_OPS_PER_ALIGNMENT,
-            "algorithmic_bytes_per_launch": P * bytes_per_alignment,
-            "hbm": {"achieved": round(P * bytes_per_alignment / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(P * bytes_per_alignment / kernel_s / 1e9 / HBM_PEAK_GBS, 5)},
-            "gcups_kernel": round(P * CELLS / kernel_s / 1e9, 1),
-        }
-        # the honest utilisation figure: VALU issue cycles the cell body needs (1 v_dot4 + 1 v_max3 + 1/4 v_max3 at 4 clk,
-        # 1 v_sub at 2 clk = 11 per wave-cell) against the cycles the launch took at the nominal clock
-        wave_cells = P * CELLS / 64.0
-        ideal_s = wave_cells * 11.0 / (256 * 4 * 2.4e9)
-        roof["issue_bound"] = {"valu_cycles_per_wave_cell": 11, "ideal_kernel_ms_at_2.4GHz": round(ideal_s * 1e3, 4),
-                               "frac": round(ideal_s / kernel_s, 4)}
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file))
-                if tr.get("pairs_per_launch") == P and args.mode == "pairs":
-                    roof["traffic"] = tr.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = tr.get("source")
-            except Exception:
-                pass
-        line = {
-            "metric": "alignments/sec (and GCUPS) on 1M fixed-length pairs, 1/2/4/8 MI355X",
-            "value": round(value, 1), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(value / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
-            "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
-            "dtype": "int32", "data": "synthetic",
-            "gcups": round(value * CELLS / 1e9, 1),
-            "config": {"workload": "%s: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, "
-                                   "inputs resident in HBM, int32 scores%s" % (
-                                       {"pairs": "BASELINE.json configs[1]", "packed": "SURVEY 8f N3 (2-bit packed inputs, source.cpp:1581)",
-                                        "one-vs-many": "SURVEY 8f N1 (every seq1 vs ONE seq2, source.cpp:1227)"}[args.mode],
-                                       P, args.match, args.mismatch, args.gap,
-                                       ", RCCL all-gather of scores each step (overlapped with the next step's kernel)" if collective else ""),
-                       "pairs_per_gpu": P, "global_pairs": n_total, "lanes_per_alignment": lanes, "schedule_flags": flags,
-                       "parallelism": "batch-sharded x%d" % world},
-            "roofline": roof, "checksum": checksum,
-        }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "pairs":
-            sample = args.cpu_sample or min(P, 1 << 20)
-            line["cpu_baseline"] = cpu_baseline(swmi, np, args, scores[0].cpu().numpy(), min(sample, P))
-            line["gpu_over_cpu_core"] = round(value / line["cpu_baseline"]["value"], 1)
-            # end-to-end through the host-buffer entry point (H2D + kernel + D2H; SURVEY 8d "reported separately"; never `value`)
-            h1, h2 = swmi.generate_pairs_host(P, args.seed, 0)
-            swmi.score_batch(h1, h2, sm, args.gap)
-            t3 = time.perf_counter()
-            hs = swmi.score_batch(h1, h2, sm, args.gap)
-            dt3 = time.perf_counter() - t3
-            line["host_buffer_path"] = {"entry": "swmi_score_batch (pageable host memory, PCIe inclusive)",
-                                        "ms": round(dt3 * 1e3, 3), "value": round(P / dt3, 1), "unit": "alignments/s",
-                                        "matches_resident_scores": bool((hs == scores[0].cpu().numpy()).all())}
+        line = bench_banded(args, swmi, np, torch, local_rank)
+    elif args.mode == "semiglobal":
+        line = bench_semiglobal(args, swmi, np, torch, local_rank)
+    elif collective:
+        line = multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank)
+    else:
+        line = single_gpu(args, swmi, np, torch, local_rank)
+    if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if collective:
         dist.barrier()

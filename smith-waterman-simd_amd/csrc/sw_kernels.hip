@@ -510,7 +510,22 @@ __device__ __forceinline__ int from_lane_above(int v)   // value of lane m+1, 0 
     return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 
-template <bool kOpenGeExt>
+// Value of lane m-1 / m+1 minus `ext`, NOT saturated: the DPP shift rides on the subtraction (v_sub*_dpp, one half-rate
+// instruction instead of v_mov_b32_dpp + v_sub_u32 clamp).  An invalid source lane reads 0, so the band's edge lanes get
+// -ext: a negative E / F acts as the "-infinity" the saturated form expressed as 0 (every consumer takes a max with a
+// value >= 0), which is why the result may stay signed.
+__device__ __forceinline__ int below_minus(int v, int ext)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - ext;
+}
+__device__ __forceinline__ int above_minus(int v, int ext)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) - ext;
+}
+
+// kI16: every H of the alignment stays below 2^15 (len * max score < 32768, decided on the host), so the two maxes that
+// form the values handed to the neighbours run as full-rate v_max_i16 (v_max_i32 is half rate on gfx950).
+template <bool kOpenGeExt, bool kI16>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
                         uint32_t n, int len, SmRows rows, int gap_open, int gap_ext)
@@ -554,39 +569,54 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
 
     if constexpr (kOpenGeExt) {
         // open >= ext (the usual case).  With hm = max(H - (open - ext), 0) both gap recurrences become
-        //   E = max(max(E_left, hm_left) - ext, 0),   F = max(max(F_up, hm_up) - ext, 0)
+        //   E = max(E_left, hm_left) - ext,   F = max(F_up, hm_up) - ext            (floored at 0, or left negative: see below)
         // (saturating subtraction distributes over max, and (H -sat (open-ext)) -sat ext = H -sat open), so a cell hands
         // its neighbours ONE value each -- me = max(E, hm) to the right, mf = max(F, hm) downwards -- and one of the two
-        // crosses lanes: 1 DPP + 3 subtractions + 2 max + dot4 + max3 per cell.
+        // crosses lanes.  The crossing one is subtracted without saturation by a v_sub_dpp (the lane shift is free on it);
+        // it may come out negative, which is harmless: it only feeds max3(t, f, e) beside a saturated partner (>= 0) and
+        // max(e, hm) beside hm >= 0.  Per cell: dot4 + max3 + sub_dpp + 2 sub + 2 max.
         const int oe = gap_open - gap_ext;
         int h0 = 0, me0 = 0, mf0 = 0;           // last cell on the even diagonal 2m
         int h1 = 0, me1 = 0, mf1 = 0;           // last cell on the odd diagonal 2m+1
-        for (int u = 0; u < len; ++u) {
-            const int b_next = (int)pb[u + 1];
-            const int a_next = (int)pa[u + 1];
+        auto pair_of_steps = [&](int b_next) {
             {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
-                const int e = sat_sub<false>(from_lane_below(me1), gap_ext);
+                const int e = below_minus(me1, gap_ext);
                 const int f = sat_sub<false>(mf1, gap_ext);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
                 const int tf = t > f ? t : f;
-                h0 = tf > e ? tf : e;           // v_max3_i32; >= 0 because e, f >= 0
+                h0 = tf > e ? tf : e;           // v_max3_i32; >= 0 because f >= 0
                 const int hm = sat_sub<false>(h0, oe);
-                me0 = e > hm ? e : hm;
-                mf0 = f > hm ? f : hm;
+                me0 = vmax<kI16>(e, hm);
+                mf0 = vmax<kI16>(f, hm);
             }
             b_cur = b_next;
             {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
                 const int e = sat_sub<false>(me0, gap_ext);
-                const int f = sat_sub<false>(from_lane_above(mf0), gap_ext);
+                const int f = above_minus(mf0, gap_ext);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
-                const int tf = t > f ? t : f;
-                h1 = tf > e ? tf : e;
+                const int te = t > e ? t : e;
+                h1 = te > f ? te : f;           // >= 0 because e >= 0
                 const int hm = sat_sub<false>(h1, oe);
-                me1 = e > hm ? e : hm;
-                mf1 = f > hm ? f : hm;
+                me1 = vmax<kI16>(e, hm);
+                mf1 = vmax<kI16>(f, hm);
             }
             const int hb = h0 > h1 ? h0 : h1;
             best = best > hb ? best : hb;
+        };
+        int u = 0;
+#pragma unroll 1
+        for (; u + 4 <= len; u += 4) {          // four iterations per trip: LDS offsets become immediates, no register rotation
+            const int b1 = (int)pb[u + 1], b2 = (int)pb[u + 2], b3 = (int)pb[u + 3], b4 = (int)pb[u + 4];
+            const int a1 = (int)pa[u + 1], a2 = (int)pa[u + 2], a3 = (int)pa[u + 3], a4 = (int)pa[u + 4];
+            pair_of_steps(b1); a_cur = a1;
+            pair_of_steps(b2); a_cur = a2;
+            pair_of_steps(b3); a_cur = a3;
+            pair_of_steps(b4); a_cur = a4;
+        }
+        for (; u < len; ++u) {
+            const int b_next = (int)pb[u + 1];
+            const int a_next = (int)pa[u + 1];
+            pair_of_steps(b_next);
             a_cur = a_next;
         }
     } else {
@@ -747,12 +777,21 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
     const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 72) * sizeof(uint32_t);
-    if (gap_open >= gap_ext)
-        hipLaunchKernelGGL(sw_banded_affine_kernel<true>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream,
-                           d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
-    else
-        hipLaunchKernelGGL(sw_banded_affine_kernel<false>, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream,
-                           d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    // 16-bit maxes are exact while no H can reach 2^15: H <= len * (largest score, at least 0)
+    int top = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const int v = (int)(int8_t)(rows.r[a] >> (8 * b));
+            top = v > top ? v : top;
+        }
+    const bool i16 = (long long)len * top < 32768 && !getenv("SWMI_BANDED_NO_I16");
+    const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+    if (gap_open >= gap_ext) {
+        if (i16) hipLaunchKernelGGL((sw_banded_affine_kernel<true, true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+        else     hipLaunchKernelGGL((sw_banded_affine_kernel<true, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    } else {
+        hipLaunchKernelGGL((sw_banded_affine_kernel<false, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+    }
     return hipGetLastError();
 }
 

@@ -1,5 +1,7 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes run the sharding + final score gather of
-swmi/sharding.py, with the CPU oracle standing in for the GPU scorer (this test checks host logic only)."""
+"""The N > 1 path on CPU: world_size-2 gloo processes run swmi/sharding.py -- shard_bounds, gather_scores and the
+GatherPipeline, the very code bench.py --gpus N runs -- with the CPU oracle standing in for the GPU scorer (this test
+checks host logic only): gather after every step (asynchronous, ring of buffers) and one final gather, equal and
+ragged shards."""
 import os
 import socket
 
@@ -20,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_total, out_dir):
+def _worker(rank, world, port, n_total, out_dir, mode, steps):
     import sys
     for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -36,19 +38,19 @@ def _worker(rank, world, port, n_total, out_dir):
         a, b = oracle.generate(n, 10000, first)
         return torch.from_numpy(a), torch.from_numpy(b)
 
-    def score(a, b):
-        return torch.from_numpy(oracle.batch(a.numpy(), b.numpy(), sm, 15))
+    def score(a, b, out):
+        out.copy_(torch.from_numpy(oracle.batch(a.numpy(), b.numpy(), sm, 15)))
 
-    full = sharding.score_sharded(score, generate, n_total)
+    full = sharding.score_sharded(score, generate, n_total, mode=mode, steps=steps)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [4096, 4097])
-def test_two_rank_shard_and_gather(tmp_path, oracle, n_total):
+@pytest.mark.parametrize("n_total,mode,steps", [(4096, "final", 1), (4097, "final", 1), (4096, "every", 6), (4097, "every", 3)])
+def test_two_rank_shard_and_gather(tmp_path, oracle, n_total, mode, steps):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), mode, steps), nprocs=world, join=True)
     a, b = oracle.generate(n_total, 10000, 0)
     want = oracle.batch(a, b, match_matrix(10, -30), 15)
     for r in range(world):

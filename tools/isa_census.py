@@ -103,16 +103,20 @@ def disassemble(lib_path=DEFAULT_LIB):
     return out
 
 
+KERNEL_NAMES = ("sw128_lut_kernel", "sw128_kernel", "sw_banded_affine_kernel", "sw_banded_affine_tile_kernel",
+                "sg_forward_split_kernel", "sg_forward_kernel", "sg_traceback_kernel", "sg_walk_lane_kernel", "sg_expand_kernel",
+                "sg_pack_streams_kernel", "generate_kernel", "unpack_kernel")
+
+
 def readable(symbol):
-    """Itanium-mangled template kernel name -> 'sw128_kernel<4,1,0,0>' style (enough for the kernels here)."""
-    m = re.search(r"\d+(sw128_kernel|sw128_lut_kernel|sw_banded_affine\w*|sg_\w+?_kernel|generate_kernel|unpack_kernel)(I(.*?)E)?Ev", symbol)
-    if not m:
-        return symbol
-    name, targs = m.group(1), m.group(3)
-    if not targs:
-        return name
-    vals = re.findall(r"L[ib](\d+)E", targs)
-    return "%s<%s>" % (name, ",".join(vals))
+    """Itanium-mangled kernel name -> 'sw128_kernel<4,1,0,0>' style (template arguments of kind int / bool only)."""
+    for name in KERNEL_NAMES:
+        m = re.search(r"\d+%s(I((?:L[a-z]\d+E)+)E)?" % name, symbol)
+        if m:
+            if not m.group(2):
+                return name
+            return "%s<%s>" % (name, ",".join(re.findall(r"L[a-z](\d+)E", m.group(2))))
+    return symbol
 
 
 def cost_of(op):
@@ -137,8 +141,10 @@ def cost_of(op):
     return "valu_unmeasured", DEFAULT_COST, DEFAULT_COST
 
 
-def census(instrs):
-    """Split a kernel at its main loop (largest backward branch) and price both parts."""
+def census(instrs, marker_op=None):
+    """Split a kernel at its main loop and price both parts.  Main loop = the backward branch with the largest body, or --
+    when marker_op names an instruction only the hot loop issues (v_dot4_i32_i8 for the scorers) -- the innermost loop that
+    holds the most of them (a staging loop can be longer than a tight DP loop)."""
     start = instrs[0]["addr"]
     loops = []
     for k, ins in enumerate(instrs):
@@ -148,6 +154,12 @@ def census(instrs):
                 first = next(i for i, x in enumerate(instrs) if x["addr"] >= tgt)
                 loops.append((first, k))
     main = max(loops, key=lambda ab: ab[1] - ab[0]) if loops else None
+    if loops and marker_op:
+        def marks(ab):
+            return sum(1 for x in instrs[ab[0]:ab[1] + 1] if re.sub(r"_(e32|e64)$", "", x["op"]) == marker_op)
+        best = max(marks(ab) for ab in loops)
+        if best > 0:
+            main = min((ab for ab in loops if marks(ab) == best), key=lambda ab: ab[1] - ab[0])
 
     def tally(seq):
         t = {"instructions": len(seq), "valu": 0, "by_class": {}, "by_op": {}, "issue_cycles_ideal": 0.0,
@@ -180,7 +192,7 @@ def census(instrs):
 _cache = {}
 
 
-def census_for(kernel_regex, lib_path=DEFAULT_LIB):
+def census_for(kernel_regex, lib_path=DEFAULT_LIB, marker_op=None):
     """{readable kernel name: census} for the kernels of lib_path whose readable name matches kernel_regex."""
     key = (os.path.abspath(lib_path), os.path.getmtime(lib_path))
     if key not in _cache:
@@ -189,7 +201,7 @@ def census_for(kernel_regex, lib_path=DEFAULT_LIB):
     for sym, instrs in _cache[key].items():
         name = readable(sym)
         if instrs and re.search(kernel_regex, name):
-            c = census(instrs)
+            c = census(instrs, marker_op)
             c["symbol"] = sym
             out[name] = c
     return out
@@ -210,13 +222,14 @@ def main():
     ap.add_argument("--lib", default=DEFAULT_LIB)
     ap.add_argument("--kernel", default=r"^sw128_kernel<4,1,0,0>$", help="regex on the readable kernel name")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--marker", default=None, help="instruction that identifies the hot loop (e.g. v_dot4_i32_i8)")
     ap.add_argument("--list", action="store_true")
     args = ap.parse_args()
     if args.list:
         for sym in disassemble(args.lib):
             print(readable(sym))
         return 0
-    res = census_for(args.kernel, args.lib)
+    res = census_for(args.kernel, args.lib, args.marker)
     if not res:
         sys.stderr.write("no kernel matches %r\n" % args.kernel)
         return 1

@@ -58,10 +58,31 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     summary["hbm_read_bytes_corrected"] = fetch_b * 2.0     # gfx950: FETCH_SIZE reports half of a wide coalesced read
     summary["hbm_write_bytes"] = write_b
     summary["hbm_bytes_per_launch"] = fetch_b * 2.0 + write_b
+# tie the numbers to the code they were taken on: hash of the kernel's instruction text in the libswmi.so of this tree
+# (tools/isa_census.py) -- bench.py quotes traffic / effective clock only while the library it times carries the same code
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+try:
+    import re
+    import isa_census
+    targs = re.search(r"sw128_kernel<([^>]*)>", summary.get("kernel", ""))
+    if targs:
+        vals = [{"true": "1", "false": "0"}.get(v.strip(), v.strip()) for v in targs.group(1).split(",")]
+        readable = "sw128_kernel<%s>" % ",".join(vals)
+        c = isa_census.census_for("^" + re.escape(readable) + "$", marker_op="v_dot4_i32_i8")
+        summary["kernel_readable"] = readable
+        summary["kernel_code_sha256"] = c[readable]["code_sha256"]
+except Exception as e:      # noqa: BLE001
+    summary["kernel_code_sha256_error"] = repr(e)
+if "GRBM_GUI_ACTIVE" in summary and "avg_ns" in summary:
+    # MI355X_MICROARCH.md, DVFS: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    summary["effective_clock_ghz"] = round(summary["GRBM_GUI_ACTIVE"] / 8.0 / summary["avg_ns"], 3)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 if "hbm_bytes_per_launch" in summary and "SQ_WAVES" in summary:
     # bench.py reads this for roofline.traffic (per launch of the default 1 048 576-pair step)
     json.dump({"pairs_per_launch": 1 << 20, "hbm_bytes_per_launch": round(summary["hbm_bytes_per_launch"]),
+               "kernel": summary.get("kernel_readable"), "kernel_code_sha256": summary.get("kernel_code_sha256"),
+               "effective_clock_ghz": summary.get("effective_clock_ghz"),
+               "sq_insts_valu_per_launch": summary.get("SQ_INSTS_VALU"),
                "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % tag},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1, sort_keys=True))
