@@ -295,7 +295,9 @@ def bench_banded(args, swmi, np, torch, local_rank, steps=None, warmup=None):
     band_cells = sum(min(length, i + 63) - max(1, i - 64) + 1 for i in range(1, length + 1))
     value = P * steps / elapsed
     # one wavefront per alignment; main loop = `length` iterations of two anti-diagonal steps (sw_banded_affine_kernel)
-    roof = issue_bound(r"^sw_banded_affine_kernel<%d>$" % (1 if args.gap_open >= args.gap_extend else 0), length, P, kernel_ms,
+    open_ge_ext = args.gap_open >= args.gap_extend
+    i16 = open_ge_ext and length * max(0, int(sm.max())) < 32768 and not os.environ.get("SWMI_BANDED_NO_I16")   # launch_banded_affine's rule
+    roof = issue_bound(r"^sw_banded_affine_kernel<%d,%d>$" % (1 if open_ge_ext else 0, 1 if i16 else 0), length, P, kernel_ms,
                        marker=("v_dot4_i32_i8", 2))
     # 12 algorithmic int ops per cell: 4 sub, 2+3 max, 1 add, 1 running max, 1 lookup (informational)
     roof.update({"kernel_ms": round(kernel_ms, 4), "traffic": None,

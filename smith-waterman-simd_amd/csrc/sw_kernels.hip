@@ -576,11 +576,14 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
         // it may come out negative, which is harmless: it only feeds max3(t, f, e) beside a saturated partner (>= 0) and
         // max(e, hm) beside hm >= 0.  Per cell: dot4 + max3 + sub_dpp + 2 sub + 2 max.
         const int oe = gap_open - gap_ext;
+        // gfx9 DPP encodings take no SGPR operand: `ext` has to sit in a VGPR for hipcc to fold the lane shift into the
+        // subtraction (v_subrev_u32_dpp); from an SGPR it emits v_mov_b32_dpp + v_subrev_u32 instead
+        const int ext_v = keep(gap_ext);
         int h0 = 0, me0 = 0, mf0 = 0;           // last cell on the even diagonal 2m
         int h1 = 0, me1 = 0, mf1 = 0;           // last cell on the odd diagonal 2m+1
         auto pair_of_steps = [&](int b_next) {
             {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
-                const int e = below_minus(me1, gap_ext);
+                const int e = below_minus(me1, ext_v);
                 const int f = sat_sub<false>(mf1, gap_ext);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
                 const int tf = t > f ? t : f;
@@ -592,7 +595,7 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
             b_cur = b_next;
             {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
                 const int e = sat_sub<false>(me0, gap_ext);
-                const int f = above_minus(mf0, gap_ext);
+                const int f = above_minus(mf0, ext_v);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
                 const int te = t > e ? t : e;
                 h1 = te > f ? te : f;           // >= 0 because e >= 0

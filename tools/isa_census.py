@@ -42,7 +42,7 @@ FULL = {  # 2-cycle class
     "v_bitop3_b32": 2.30, "v_accvgpr_write_b32": 2.21, "v_accvgpr_read_b32": 2.21, "v_accvgpr_mov_b32": 2.21,
 }
 HALF = {  # 4-cycle class
-    "v_max_i32": 4.09, "v_max_u32": 4.15, "v_min_i32": 4.13, "v_min_u32": 4.15, "v_max3_i32": 4.13, "v_min3_i32": 4.17,
+    "v_max_i32": 4.09, "v_max_u32": 4.15, "v_max3_u32": 4.15, "v_min3_u32": 4.15, "v_min_i32": 4.13, "v_min_u32": 4.15, "v_max3_i32": 4.13, "v_min3_i32": 4.17,
     "v_med3_i32": 4.25, "v_dot4_i32_i8": 4.17, "v_dot4c_i32_i8": 4.12, "v_perm_b32": 4.16, "v_bfe_i32": 4.16,
     "v_bfe_u32": 4.16, "v_add3_u32": 4.17, "v_lshl_add_u32": 4.17, "v_lshl_or_b32": 4.16, "v_and_or_b32": 4.18,
     "v_or3_b32": 4.17, "v_xad_u32": 4.17, "v_alignbit_b32": 4.17, "v_alignbyte_b32": 4.17, "v_bfi_b32": 4.17,
