@@ -402,7 +402,9 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     name = sweep_kernel.replace(" ", "")
     # wavefronts of the sweep: 32 / 16 alignments per wavefront with the band over 2 / 4 lanes, 2 with a band per half-wavefront
     per_wave = {"sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(name.split(",")[0], 2)
-    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms)
+    # the split sweep's round loop is unrolled by two; one v_alignbit per cell + the stream / window shifts mark a round
+    marker = {"sg_forward_split_kernel<2": ("v_alignbit_b32", 18), "sg_forward_split_kernel<4": ("v_alignbit_b32", 9)}.get(name.split(",")[0])
+    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker)
     traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
     roof.update({
         "kernel_ms": round(sweep_ms, 3), "traceback_kernels": tb_kernel, "traceback_kernel_ms": round(tb_ms, 3),

@@ -32,6 +32,17 @@ constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 6560
 constexpr size_t kSplit4MinBatch = 6144;         // band over 4 (later 2) lanes from here on
 constexpr size_t kLaneTracebackMinBatch = 3072;  // one lane per walk (+ expand kernel) from here on
 
+// summary[a].z = band lane of the best cell | kTagFormat when the alignment's code records are in the split sweep's tag
+// format (64 bits per round, band cell k at bits 2k..2k+1: 3 diagonal, 2 up, 1 left) instead of the half-wavefront
+// sweep's two 32-bit words (bit k of word 0 / word 1 = low / high bit of the code 1 diagonal, 2 up, 3 left)
+constexpr int kTagFormat = 1 << 8;
+__device__ __forceinline__ unsigned decode_code(uint2 cw, int bl, bool tag_format)
+{
+    const unsigned two_words = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
+    const unsigned tag = ((bl & 16 ? cw.y : cw.x) >> (2 * (bl & 15))) & 3u;
+    return tag_format ? (4u - tag) & 3u : two_words;
+}
+
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
 __device__ __forceinline__ int row16_max(int v)
 {
@@ -145,7 +156,6 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     if (writer) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
 }
 
-constexpr int kNeg = -(1 << 24);                       // a dropped cell in the split sweep (the reference stores 0)
 
 // ---- character streams for the split sweep -------------------------------------------------------------------------
 //
@@ -190,22 +200,33 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
 // ---- sweep, G lanes per alignment (C = 32 / G band cells per lane) -------------------------------------------------
 //
 // Same results as sg_forward_kernel, different mapping: each lane keeps C cells of the band in registers, so most of a
-// round is plain per-lane arithmetic (~14 instructions per cell, against ~58 per one-cell lane above, most of those
-// cross-lane plumbing).  What crosses lanes per round is small: the two cells next to the lane's slice, one sequence
-// character in each direction, the band's two end cells (direction) and the band maximum -- all DPP moves inside a row
-// of 16 lanes.  (A whole band per lane, G = 1, was the first version: 64 alignments per wavefront and ~200 VGPRs leave
-// one or two wavefronts per SIMD and nothing to hide latencies behind; it lost to G = 2 and G = 4 at every batch size.)
-//   * dropped cells hold kNeg instead of 0: the != 0 guards of source.cpp:1922-1924 then fall out of max3, and the
-//     X-drop test "v < max(best - 70, 1)" resets every dropped cell to exactly kNeg each round;
-//   * one shifted view S[j] = right ? P[j] : P[j-1] of the previous round's cells serves as `left` (S[k]) and `up`
-//     (S[k+1]); last round's view gives the diagonal (right ? S'[k+1] : S'[k]): two selects per cell and C+1 registers;
-//     the -1 of the gap is applied to the view once, not per use;
+// round is plain per-lane arithmetic.  What crosses lanes per round is small: the two cells next to the lane's slice, one
+// sequence character in each direction, the band's two end cells (direction) and the band maximum -- all DPP moves inside
+// a row of 16 lanes.  (A whole band per lane, G = 1, was the first version: 64 alignments per wavefront and ~200 VGPRs
+// leave one or two wavefronts per SIMD and nothing to hide latencies behind; it lost to G = 2 and G = 4 at every batch size.)
+//
+// The cell (round 2 form: 32 VALU issue cycles per cell, was ~55).  A cell value travels as ONE tagged integer
+//     V = value * 128 + band_cell * 4 + tag                      (kScale = 128: 5 bits of cell index, 2 bits of tag)
+// and the three candidates of a cell carry the tags 3 (diagonal), 2 (up), 1 (left).  Then
+//   * V0 = v_max3(VD, VU, VL) yields the cell's value AND, in its low two bits, which predecessor won -- with the
+//     reference's tie-break order (diagonal, then up, then left; source.cpp:1962-1971) because equal values compare by tag.
+//     No compares, no subtractions: ONE v_alignbit per cell shifts the two tag bits into the lane's code word;
+//   * all three candidates of a cell carry the same cell index, so the index never influences the cell's own max, while
+//     the band maximum max(V0 over cells and lanes) is decided by value, then by the HIGHEST cell index among equals --
+//     where the reference's search stops (source.cpp:1957-1958); the tag never matters there (indices differ);
+//   * the "-1" of a gap move and of a mismatch is folded into the per-candidate constant (cell * 4 + tag - 128), a match
+//     adds 256;
+//   * a dropped cell holds value -1 (the reference stores 0 and guards with != 0, source.cpp:1922-1924): every candidate
+//     derived from dropped cells is <= 0 < max(best - 70, 1) and is dropped again by the X-drop test, which also strips
+//     index and tag: cur = (V0 | sign(V0 - threshold)) & clean_mask -- sub, shift, v_bitop3, all full rate;
+//   * the shifted views S[j] = right ? P[j] : P[j-1] (left = S[c], up = S[c+1]; last round's view gives the diagonal) are
+//     bitwise selects with a per-lane all-ones / all-zeros mask: v_bitop3_b32 (full rate) instead of v_cndmask (half);
 //   * sequence characters are 4-bit fields (0..3, pads 8 / 4: a pad never matches) in one window per sequence, cell c <->
-//     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells;
-//   * the band maximum and the cell that holds it come from one max over keys (value << 5 | cell);
-//   * predecessor codes are collected as two C-bit words per round (vd != v, vu != v), shifted in as the sign of the
-//     difference; dropped cells carry no "live" bit: a path never enters a dropped cell (its value cannot equal a live
-//     cell's predecessor value), so the traceback never reads that bit.
+//     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells.
+// Stored value of a cell between rounds: value * 128 + (first cell of the lane) * 4  ("clean"; the lane's share of the
+// index stays in, the cell's own share and the tag are added with the candidate constants).
+constexpr int kScale = 128;
+
 template <int G, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
@@ -228,7 +249,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const uint32_t a = real ? a0 : n - 1;
     const unsigned long long *stream_a = streams + (size_t)a * (2 * kStreamWords);
     const unsigned long long *stream_b = stream_a + kStreamWords;
-    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 8);       // this slice's bytes of word 0
+    // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
+    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 4);
     auto flush_codes = [&](int g8) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -273,13 +295,22 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
         return v;
     };
+    // bitwise select with an all-ones / all-zeros mask: ONE full-rate v_bitop3_b32 (truth table 0xCA = a ? b : c).  Written
+    // as (b & m) | (c & ~m) hipcc picks v_bfi_b32, written as ?: v_cndmask_b32 -- both half rate on gfx950.
+    auto pick = [](int m, int if_set, int if_clear) { return (int)__builtin_amdgcn_bitop3_b32((unsigned)m, (unsigned)if_set, (unsigned)if_clear, 0xCA); };
 
-    int cur[C], spm[C + 1];                               // cells of the previous round; its shifted view minus 1
+    const int lane_base = (g * C) << 2;                   // this lane's share of the cell index, where a value carries it
+    const int clean_mask = keep_opaque(~(kScale - 1) | lane_base);            // also the dropped cell: value -1, clean
+    const int kDropped = clean_mask;
+    const int first_mask = keep_opaque(is_first ? -1 : 0), last_mask = keep_opaque(is_last ? -1 : 0);
+    // Clean cells of the previous round, and its shifted view S in TWO register sets that swap roles every round (the
+    // round loop is unrolled by two): a single set costs a register copy per cell per round.
+    int cur[C], sp_a[C + 1], sp_b[C + 1];
 #pragma unroll
-    for (int c = 0; c < C; ++c) cur[c] = kNeg;
+    for (int c = 0; c < C; ++c) cur[c] = kDropped;
 #pragma unroll
-    for (int c = 0; c <= C; ++c) spm[c] = kNeg;
-    if (is_last) cur[C - 1] = kXDrop;
+    for (int c = 0; c <= C; ++c) sp_a[c] = sp_b[c] = kDropped;
+    if (is_last) cur[C - 1] = kXDrop * kScale + lane_base;
     // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
     win_t aw = 0, bw = 0;
     {
@@ -306,16 +337,27 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         s_lo = (unsigned)w; s_hi = (unsigned)(w >> 32);
         n_lo = (unsigned)nw; n_hi = (unsigned)(nw >> 32);
     }
+    auto pick_win = [&](int m, win_t if_set, win_t if_clear) -> win_t {
+        if constexpr (C == 8) {
+            return (win_t)pick(m, (int)if_set, (int)if_clear);
+        } else {
+            const unsigned lo = (unsigned)pick(m, (int)(unsigned)if_set, (int)(unsigned)if_clear);
+            const unsigned hi = (unsigned)pick(m, (int)(unsigned)(if_set >> 32), (int)(unsigned)(if_clear >> 32));
+            return ((win_t)hi << 32) | lo;
+        }
+    };
 
-    for (int round = 1; round < kMaxRound; ++round) {
-        if (!__any(alive)) break;
-        const bool right = group_first(cur[0]) < group_last(cur[C - 1]);      // source.cpp:1895
-        pos_x += right ? 1 : 0;
+    // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
+    auto one_round = [&](const int round, const int (&sp)[C + 1], int (&sp_next)[C + 1]) {
+        // source.cpp:1895: band cell 0 against band cell 31 (the last lane's values carry its share of the index)
+        const bool right = group_first(cur[0]) + (((G - 1) * C) << 2) < group_last(cur[C - 1]);
+        const int rmask = keep_opaque(right ? -1 : 0);
+        pos_x -= rmask;                                   // += 1 when the band steps right
         const int pos_y = round - (pos_x - 31);
         alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
-        // neighbours of the slice in the previous round's band
-        const int p_lo = from_prev(cur[C - 1]), p_hi = from_next(cur[0]);
-        const int lo_in = is_first ? kNeg : p_lo, hi_in = is_last ? kNeg : p_hi;
+        // neighbours of the slice in the previous round's band, re-based to this lane's share of the index
+        const int p_lo = from_prev(cur[C - 1]) + (C << 2), p_hi = from_next(cur[0]) - (C << 2);
+        const int lo_in = pick(first_mask, kDropped, p_lo), hi_in = pick(last_mask, kDropped, p_hi);
         // sequence windows follow the band
         {
             const unsigned cand = s_lo & 15u;             // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
@@ -323,18 +365,18 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             // (the DPP moves are evaluated by ALL lanes before the select: inside one arm of `?:` they would run with the
             // source lanes masked off)
             const unsigned a_nb = (unsigned)from_prev((int)a_top), b_nb = (unsigned)from_next((int)b_low);
-            const unsigned a_in = is_first ? cand : a_nb;
-            const unsigned b_in = is_last ? cand : b_nb;
+            const unsigned a_in = (unsigned)pick(first_mask, (int)cand, (int)a_nb);
+            const unsigned b_in = (unsigned)pick(last_mask, (int)cand, (int)b_nb);
             const win_t aw_d = (aw << 4) | a_in;
             const win_t bw_r = (bw >> 4) | ((win_t)b_in << (4 * C - 4));
-            aw = right ? aw : aw_d;
-            bw = right ? bw_r : bw;
-            const bool consume = is_last ? right : !right;
+            aw = pick_win(rmask, aw, aw_d);
+            bw = pick_win(rmask, bw_r, bw);
+            const int cmask = keep_opaque(~(rmask ^ last_mask));              // consume = is_last ? right : !right
             const unsigned sh_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, 4), sh_hi = s_hi >> 4;
-            s_lo = consume ? sh_lo : s_lo;
-            s_hi = consume ? sh_hi : s_hi;
-            s_idx += consume ? 1 : 0;
-            if (consume && (s_idx & 15) == 0) {           // sixteen consumed: take the prefetched word, request the one after
+            s_lo = (unsigned)pick(cmask, (int)sh_lo, (int)s_lo);
+            s_hi = (unsigned)pick(cmask, (int)sh_hi, (int)s_hi);
+            s_idx -= cmask;
+            if (cmask != 0 && (s_idx & 15) == 0) {        // sixteen consumed: take the prefetched word, request the one after
                 s_lo = n_lo; s_hi = n_hi;
                 const int next_word = (s_idx >> 4) + 1;   // a band that has left the matrix keeps stepping: stay inside the stream
                 const unsigned long long nw = my_stream[next_word < kStreamWords ? next_word : kStreamWords - 1];
@@ -344,59 +386,68 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         win_t z = aw ^ bw;
         z |= z >> 1;
         z |= z >> 2;
-        const win_t m2 = (~z & kOnes) << 1;               // field c = 2 (match) or 0
-        const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)((unsigned long long)m2 >> 32);
+        const win_t mt = ~z & kOnes;                      // bit 4c set: cell c is a match
+        const unsigned mt_lo = (unsigned)mt, mt_hi = (unsigned)((unsigned long long)mt >> 32);
 
-        int kmax = kNeg;
-        unsigned w_nd = 0, w_nu = 0;                      // bit c: vd != v0 / vu != v0, shifted in as the sign of the difference
-        int sm_hi = (right ? hi_in : cur[C - 1]) - 1;     // S[C] - 1
+        int kmax = (int)0x80000000;
+        unsigned tags = 0;                                // two tag bits per cell, cell c ends up at bits 2c (C = 16) / 16 + 2c (C = 8)
+        int s_lo_v = pick(rmask, cur[0], lo_in);          // S[0]
 #pragma unroll
-        for (int c = C - 1; c >= 0; --c) {
-            const int below = c > 0 ? cur[c - 1] : lo_in;
-            const int sm_lo = (right ? cur[c] : below) - 1;                   // S[c] - 1 = left - 1 (:1923); sm_hi = up - 1 (:1924)
-            const int dm1 = right ? spm[c + 1] : spm[c];                      // diagonal - 1 (:1897 / :1908)
-            const int f = (int)__builtin_amdgcn_ubfe(c < 8 ? m2lo : m2hi, 4 * (c & 7), 2);
-            const int vd = dm1 + f;                       // +1 / -1, :1918-1922
-            const int m1 = vd > sm_hi ? vd : sm_hi;
-            const int v0 = m1 > sm_lo ? m1 : sm_lo;
-            const int key = (int)(((unsigned)v0 << 5) | (unsigned)(g * C + c));
-            kmax = kmax > key ? kmax : key;
-            w_nd = __builtin_amdgcn_alignbit(w_nd, (unsigned)(vd - v0), 31);  // (w << 1) | sign(vd - v0); v0 >= vd always
-            w_nu = __builtin_amdgcn_alignbit(w_nu, (unsigned)(sm_hi - v0), 31);
-            spm[c + 1] = sm_hi;
-            cur[c] = v0;
-            sm_hi = sm_lo;
+        for (int c = 0; c < C; ++c) {
+            const int above = c + 1 < C ? cur[c + 1] : hi_in;                 // P[c+1]
+            const int s_hi_v = pick(rmask, above, cur[c]);                    // S[c+1]: up (:1899-1900 / :1909)
+            const int dsel = pick(rmask, sp[c + 1], sp[c]);                   // diagonal (:1897 / :1908)
+            const unsigned mw = c < 8 ? mt_lo : mt_hi;
+            const int sh = 4 * (c & 7) - 8;                                   // match bit -> bit 8 = 2 * kScale
+            const int f = (int)((sh >= 0 ? mw >> sh : mw << -sh) & (2u * kScale));
+            const int vd = dsel + f + ((c << 2) + 3 - kScale);                // dia + 1 / dia - 1, tag 3   (:1918-1922)
+            const int vu = s_hi_v + ((c << 2) + 2 - kScale);                  // up - 1, tag 2              (:1924)
+            const int vl = s_lo_v + ((c << 2) + 1 - kScale);                  // left - 1, tag 1            (:1923)
+            const int m1 = vd > vu ? vd : vu;
+            const int v0 = m1 > vl ? m1 : vl;                                 // v_max3_i32: value, cell, winning tag
+            kmax = kmax > v0 ? kmax : v0;
+            tags = __builtin_amdgcn_alignbit((unsigned)v0, tags, 2);          // (tags >> 2) | (tag << 30)
+            sp_next[c] = s_lo_v;
+            cur[c] = v0;                                  // (tagged until the X-drop pass below cleans it)
+            s_lo_v = s_hi_v;
         }
-        spm[0] = sm_hi;
+        sp_next[C] = s_lo_v;
         kmax = group_max(kmax);
-        const int band_best = kmax >> 5;                  // arithmetic shift: the value part of the winning key
+        const int band_best = kmax >> 7;                  // arithmetic shift: the value part of the winner
         const int round_best = band_best > 0 ? band_best : 0;
         const bool improved = alive && round_best > best; // :1933-1936
-        best = improved ? round_best : best;
-        best_round = improved ? round : best_round;
-        best_lane = improved ? (kmax & 31) : best_lane;   // highest lane among equals: where the search of :1957 stops
-        const int thr = best - kXDrop > 1 ? best - kXDrop : 1;                // :1938-1941, and "0 means dropped"
+        const int imask = keep_opaque(improved ? -1 : 0);
+        best = pick(imask, round_best, best);
+        best_round = pick(imask, round, best_round);
+        best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
+        const int thr = (best - kXDrop > 1 ? best - kXDrop : 1) * kScale;     // :1938-1941, and "0 means dropped"
 #pragma unroll
-        for (int c = 0; c < C; ++c) cur[c] = cur[c] < thr ? kNeg : cur[c];
-        // codes 1 / 2 / 3 = diag / up / left (:1962-1971): low bit = diagonal or not up, high bit = not diagonal
-        const unsigned word0 = ~w_nd | w_nu, word1 = w_nd;
-        if (C == 8) {
-            my_stage0[8 * (round & 7)] = (uint8_t)word0;
-            my_stage0[8 * (round & 7) + 4] = (uint8_t)word1;
-        } else {
-            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7)) = (uint16_t)word0;
-            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7) + 4) = (uint16_t)word1;
+        for (int c = 0; c < C; ++c) {
+            // sub, shift, v_bitop3_b32 (0xA8 = (a | b) & c), all full rate; opaque, or hipcc turns it back into a half-rate
+            // v_cmp + v_cndmask pair.  Dropped -> kDropped, live -> cell index and tag stripped.
+            const int below_thr = keep_opaque(cur[c] - thr) >> 31;   // (opaque difference: `(a - b) >> 31` alone becomes cmp + select)
+            cur[c] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[c], (unsigned)below_thr, (unsigned)clean_mask, 0xA8);
         }
+        if (C == 8) *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7)) = (uint16_t)(tags >> 16);
+        else        *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 7)) = tags;
         if (is_first) stage_top[al][round & 31] = (uint16_t)pos_y;
         if ((round & 7) == 7) flush_codes(round >> 3);
         if ((round & 31) == 31) flush_top(round >> 5);
         rounds = alive ? round + 1 : rounds;
         alive = alive && round_best != 0;                 // :1943-1946
         last_round = round;
+    };
+
+    for (int round = 1; round < kMaxRound; round += 2) {  // kMaxRound is odd: rounds 1 .. kMaxRound - 1 in pairs
+        if (!__any(alive)) break;
+        one_round(round, sp_a, sp_b);
+        if (!__any(alive)) break;
+        one_round(round + 1, sp_b, sp_a);
     }
     if ((last_round & 7) != 7) flush_codes(last_round >> 3);
     if ((last_round & 31) != 31) flush_top(last_round >> 5);
-    if (real && is_first) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
+    // .z: the best cell's band lane, and bit 8 = "code records in tag format" (cell k at bits 2k: 3 diag, 2 up, 1 left)
+    if (real && is_first) summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, rounds);
 }
 
 // Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
@@ -412,7 +463,9 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     const int lane = threadIdx.x;
     const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride;
     const uint16_t *my_top = top_y + (size_t)a * kTopStride;
-    const int4 sum = summary[a];
+    int4 sum = summary[a];
+    const bool tag_format = (sum.z & kTagFormat) != 0;
+    sum.z &= 31;
     const int y0 = (int)my_top[sum.y] + 31 - sum.z;
     const int x0 = sum.y - y0;
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
@@ -454,7 +507,7 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
                 const unsigned lo = __builtin_amdgcn_readlane(cw.x, idx), hi = __builtin_amdgcn_readlane(cw.y, idx);
                 const int top = __builtin_amdgcn_readlane(tw, idx);
                 const int bl = 31 - (y - top);
-                const int code = (int)((lo >> bl) & 1u) | (int)(((hi >> bl) & 1u) << 1);
+                const int code = (int)decode_code(make_uint2(lo, hi), bl, tag_format);
                 if (code == 1) { --y; --x; }
                 else if (code == 2) { --y; }
                 else if (code == 3) { --x; }
@@ -511,7 +564,9 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
     const uint4 *my_top = reinterpret_cast<const uint4 *>(top_y + (size_t)a * kTopStride);
     unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
-    const int4 sum = summary[a];
+    int4 sum = summary[a];
+    const bool tag_format = (sum.z & kTagFormat) != 0;
+    sum.z &= 31;
     int y = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
@@ -544,7 +599,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
             const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
             const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
             const int bl = 31 - (y - top);
-            const unsigned code = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);   // never 0 on a live path
+            const unsigned code = decode_code(cw, bl, tag_format);                   // never 0 on a live path
             y -= (code == 1 || code == 2) ? 1 : 0;        // 1 diag, 2 up: one row back
             x -= (code == 1 || code == 3) ? 1 : 0;        // 1 diag, 3 left: one column back
             const unsigned sh = 2 * (steps & 15u);
