@@ -57,11 +57,13 @@ REFERENCE_PUBLISHED_ALIGN_PER_S = 1e6 / 4.4    # README.md:4 of the reference: s
 CONFIG3_PAIRS_PER_GPU = 1 << 26                # BASELINE.json configs[3]: 512M pairs over 8 GPUs
 
 
-def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None):
+def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None, conditional_share=1.0):
     """VALU issue-bound utilisation of one launch, derived from the shipped library's disassembly (tools/isa_census.py).
 
     `trips` = iterations of the main loop AS WRITTEN IN THE SOURCE; `marker` = (mnemonic, count per source iteration):
     hipcc unrolls some instantiations, and the number of marker instructions in the compiled loop body says by how much.
+    `conditional_share` = on which share of the iterations the loop's blocks under a scalar condition run (the semi-global
+    sweep flushes its records every 16th round).
     Returns the dict that goes into a `roofline` object: achieved / peak in G SIMD-issue-cycles per second and
     frac = achieved / peak <= 1 by construction (a kernel cannot issue more VALU cycles than elapsed)."""
     try:
@@ -71,7 +73,7 @@ def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None):
             raise RuntimeError("%d kernels match %r" % (len(found), kernel_regex))
         name, c = next(iter(found.items()))
         if marker:
-            unroll = c["main_loop"]["by_op"].get(marker[0], 0) / float(marker[1])
+            unroll = (c["main_loop"]["by_op"].get(marker[0], 0)) / float(marker[1])
             if unroll < 1:
                 raise RuntimeError("main loop of %s holds %d %s, fewer than one source iteration's %d" % (
                     name, c["main_loop"]["by_op"].get(marker[0], 0), marker[0], marker[1]))
@@ -79,8 +81,8 @@ def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None):
     except Exception as e:                  # no llvm-objdump on this box: say so, never invent a fraction
         return {"frac": None, "census_error": repr(e)}
     kernel_s = kernel_ms * 1e-3
-    cyc_ideal = isa_census.issue_cycles_per_wave(c, trips, "ideal")
-    cyc_meas = isa_census.issue_cycles_per_wave(c, trips, "measured")
+    cyc_ideal = isa_census.issue_cycles_per_wave(c, trips, "ideal", conditional_share)
+    cyc_meas = isa_census.issue_cycles_per_wave(c, trips, "measured", conditional_share)
     achieved = waves * cyc_ideal / kernel_s
     return {
         "bound": "valu", "kernel": name, "kernel_code_sha256": c["code_sha256"],
@@ -89,10 +91,12 @@ def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None):
         "frac_at_measured_instruction_rates": round(waves * cyc_meas / kernel_s / SIMD_CYCLES_PER_S, 4),
         "census": {"source": "tools/isa_census.py on the libswmi.so being timed (class costs: profiles/r01_microbench_valu_rate*.txt)",
                    "main_loop_trips": round(trips, 2), "wavefronts_per_launch": waves,
-                   "valu_instructions_per_wavefront": round(isa_census.valu_instructions_per_wave(c, trips)),
+                   "valu_instructions_per_wavefront": round(isa_census.valu_instructions_per_wave(c, trips, conditional_share)),
                    "issue_cycles_per_wavefront": round(cyc_ideal, 1),
                    "main_loop_valu_by_op": c["main_loop"]["by_op"],
                    "main_loop_issue_cycles": c["main_loop"]["issue_cycles_ideal"],
+                   "main_loop_conditional_issue_cycles": c["main_loop_conditional"]["issue_cycles_ideal"],
+                   "conditional_share": conditional_share,
                    "unmeasured_valu_in_main_loop": c["main_loop"]["unmeasured_valu"]},
     }
 
@@ -403,8 +407,11 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     # wavefronts of the sweep: 32 / 16 alignments per wavefront with the band over 2 / 4 lanes, 2 with a band per half-wavefront
     per_wave = {"sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(name.split(",")[0], 2)
     # the split sweep's round loop is unrolled by two; one v_alignbit per cell + the stream / window shifts mark a round
-    marker = {"sg_forward_split_kernel<2": ("v_alignbit_b32", 18), "sg_forward_split_kernel<4": ("v_alignbit_b32", 9)}.get(name.split(",")[0])
-    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker)
+    # (per round: one v_alignbit per cell, one for the move bit, one / two for the stream and window shifts)
+    marker = {"sg_forward_split_kernel<2": ("v_alignbit_b32", 19), "sg_forward_split_kernel<4": ("v_alignbit_b32", 10)}.get(name.split(",")[0])
+    # the record flush + stream top-up block runs on every 16th round; the loop holds two rounds and hipcc keeps one copy
+    # of the block behind each, so of the conditional instructions the census finds in a trip 1/16 run on average
+    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker, conditional_share=1.0 / 16)
     traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
     roof.update({
         "kernel_ms": round(sweep_ms, 3), "traceback_kernels": tb_kernel, "traceback_kernel_ms": round(tb_ms, 3),

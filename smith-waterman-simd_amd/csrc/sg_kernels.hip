@@ -26,8 +26,10 @@ constexpr int kLen = 16384;                 // std::array<uint8_t,16384>, source
 constexpr int kXDrop = 70;                  // X_THRESHOLD, source.cpp:1848
 constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
 // per-alignment row strides of the sweep's records, padded so that every alignment starts on a 64-byte line
-constexpr int kCodeStride = (kMaxRound + 7) & ~7;        // uint2 entries (8 B): 262208 B per alignment
-constexpr int kTopStride = (kMaxRound + 31) & ~31;       // uint16 entries: 65600 B per alignment
+constexpr int kCodeStride = (kMaxRound + 15) & ~15;      // uint2 entries (8 B): 262272 B per alignment = 2049 lines of 128 B
+// move bits: bit (r & 31) of word r >> 5 = 1 when the band stepped right in round r (source.cpp:1895); stored
+// word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
+constexpr int kDirWords = kMaxRound / 32 + 1;
 // which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
 constexpr size_t kSplit4MinBatch = 6144;         // band over 4 (later 2) lanes from here on
 constexpr size_t kLaneTracebackMinBatch = 3072;  // one lane per walk (+ expand kernel) from here on
@@ -66,8 +68,8 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 }
 
 // codes[(a * kMaxRound + r) * 2 + {0,1}]: bit k of word 0 / word 1 = low / high bit of lane k's predecessor code
-// (0 none or dropped, 1 diagonal, 2 up, 3 left); top_y[a * kMaxRound + r] = row of lane 31 in round r;
-// summary[a] = {score, best_round, best_lane, rounds stored}
+// (0 none or dropped, 1 diagonal, 2 up, 3 left); dirs = the band's move bits (above);
+// summary[a] = {score, best_round, best_lane (| kTagFormat), row of the band's top cell in best_round}
 //
 // A round is one long dependency chain and the kernel is bound by how many instructions it issues per round (8 waves
 // per SIMD keep the issue port busy), so the body is branch-free and every cross-lane step is a DPP move or a v_readlane:
@@ -76,7 +78,7 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 template <int W>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
-                  uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
+                  uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
 {
     const int lane = threadIdx.x & 63;
     const int k = lane & 31;                              // lane of the band, as the reference numbers them
@@ -88,16 +90,17 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     if (!real) a = n - 1;                                 // odd tail: shadow the last alignment, store nothing
     const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
     uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kCodeStride;
-    uint16_t *my_top = top_y + (size_t)a * kTopStride;
+    uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
     const int not_first = keep_opaque(k == 0 ? 0 : -1), not_last = keep_opaque(k == 31 ? 0 : -1);
     const bool writer = real && k == 0;
 
     int cur = k == 31 ? kXDrop : 0, hor = 0, ver = 0, dia = 0;
     int pos_x = 31;                                       // the reference's now_pos_x (31 leading pads); now_pos_y = round - (pos_x - 31)
-    int best = kXDrop, best_round = 0, best_lane = 31;
+    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0;
     bool alive = true;
-    int rounds = 1;
-    if (writer) { my_codes[0] = make_uint2(0, 0); my_top[0] = 0; }
+    unsigned dir_word = 0;                                // move bits of the current 32 rounds: round r enters at bit 31, ends at bit r & 31
+    int last_round = 0;
+    if (writer) my_codes[0] = make_uint2(0, 0);
 
     for (int round = 1; round < kMaxRound; ++round) {
         if (!__any(alive)) break;
@@ -113,6 +116,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         hor = nh;
         ver = nv;
         pos_x += right ? 1 : 0;
+        dir_word = (dir_word >> 1) | (right ? 0x80000000u : 0u);
         const int pos_y = round - (pos_x - 31);
         const bool inside = pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;      // :1903, :1913: checked before the round is stored
         alive = alive && inside;
@@ -139,6 +143,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         best = improved ? gain : best;
         best_round = improved ? round : best_round;
         best_lane = improved ? 31 - __builtin_clz(mine) : best_lane;          // the search of :1957-1958 walks down from lane 31
+        best_top = improved ? pos_y : best_top;
         const int v = v0 < best - kXDrop ? 0 : v0;        // :1938-1941
         // predecessor code in the reference's tie-break order (diag, up, left; :1962-1971): 1 / 2 / 3, 0 for a dropped cell.
         // v != 0 && vd == v implies dia != 0 (and likewise for up), so three compare masks are enough.
@@ -147,13 +152,16 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         if (alive && writer) {
             my_codes[round] = second ? make_uint2((unsigned)(bit0 >> 32), (unsigned)(bit1 >> 32))
                                      : make_uint2((unsigned)bit0, (unsigned)bit1);
-            my_top[round] = (uint16_t)pos_y;
         }
+        if ((round & 31) == 31 && writer) my_dirs[(size_t)(round >> 5) * n] = dir_word;
         cur = alive ? v : cur;
-        rounds = alive ? round + 1 : rounds;
         alive = alive && round_best != 0;                 // :1943-1946
+        last_round = round;
     }
-    if (writer) summary[a] = make_int4(best - kXDrop, best_round, best_lane, rounds);
+    if (writer) {
+        if ((last_round & 31) != 31) my_dirs[(size_t)(last_round >> 5) * n] = dir_word >> (31 - (last_round & 31));
+        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
+    }
 }
 
 
@@ -230,15 +238,16 @@ constexpr int kScale = 128;
 template <int G, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
-                        uint32_t *__restrict__ codes, uint16_t *__restrict__ top_y, int4 *__restrict__ summary)
+                        uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
 {
     constexpr int C = 32 / G;                             // band cells per lane
     constexpr int A = 64 / G;                             // alignments per wavefront
     static_assert(G == 2 || G == 4, "the cross-lane moves below are written for quads");
     using win_t = typename std::conditional<C == 8, uint32_t, unsigned long long>::type;   // C 4-bit fields
     constexpr win_t kOnes = (win_t)0x1111111111111111ull;
-    __shared__ uint2 stage_codes[A][8];                   // [alignment of the block][round & 7]
-    __shared__ uint16_t stage_top[A][32];                 // [alignment of the block][round & 31]
+    // sixteen rounds of code records per alignment are staged here and leave as ONE 128-byte line per alignment: a
+    // 64-byte piece of a 128-byte L2 line costs a read-for-ownership of the whole line on top of the write
+    __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]
     const int lane = threadIdx.x;
     const int g = lane & (G - 1);                         // slice of the band: cells g*C .. g*C + C-1
     const int al = lane / G;                              // alignment of the block
@@ -251,29 +260,17 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const unsigned long long *stream_b = stream_a + kStreamWords;
     // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
     uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 4);
-    auto flush_codes = [&](int g8) {
+    uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
+    auto flush_codes = [&](int g16) {                     // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int q = 0; q < A / 16; ++q) {
-            const int fa = q * 16 + (lane >> 2), part = lane & 3;
+        for (int q = 0; q < A / 8; ++q) {                 // 8 alignments x 128 B per store instruction
+            const int fa = q * 8 + (lane >> 3), part = lane & 7;
             const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
             if (block_first + fa < n)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + fa) * kCodeStride + 8 * g8 + 2 * part) = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto flush_top = [&](int g32) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int q = 0; q < A / 16; ++q) {
-            const int fa = q * 16 + (lane >> 2), part = lane & 3;
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_top[fa][8 * part]);
-            if (block_first + fa < n)
-                *reinterpret_cast<uint4 *>(top_y + (size_t)(block_first + fa) * kTopStride + 32 * g32 + 8 * part) = v;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + fa) * kCodeStride + 16 * g16 + 2 * part) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -324,19 +321,52 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
     }
     int pos_x = 31;
-    int best = kXDrop, best_round = 0, best_lane = 31, rounds = 1, last_round = 0;
+    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
     bool alive = true;
-    if (is_first) { stage_codes[al][0] = make_uint2(0, 0); stage_top[al][0] = 0; }
+    unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
+    if (is_first) stage_codes[al][0] = make_uint2(0, 0);
     // This lane's character stream: the first slice feeds on seq1 (consumed when the band steps down), the last slice on
     // seq2 (consumed when it steps right); slices in between run the seq1 stream along without using it.
+    //   sreg   the next 16 characters, next one in the low field; a consume shifts it by one field (zeros come in)
+    //   pend   characters after those (p_fill of them, low-aligned, zeros above), ahead: the word after pend (a load
+    //          issued at the previous top-up), w_next: index of the word after `ahead`
+    // Every 16 rounds -- a lane consumes at most 16 characters in 16 rounds -- one block, at the same place for every lane,
+    // tops sreg up to 16 characters again from pend / ahead and requests the next word.  The round loop itself holds no
+    // load and no wait: with the refill inside the round, hipcc keeps the prefetched word in a register pair of its own
+    // and copies it every round, which puts an s_waitcnt vmcnt(0) -- on the load AND on the record stores -- into every round.
     const unsigned long long *my_stream = is_last ? stream_b : stream_a;
-    int s_idx = is_last ? 0 : 31;                         // next character: seq2[0] / seq1[31]
-    unsigned s_lo, s_hi, n_lo, n_hi;                      // shift register (next character in the low field), prefetched word
+    unsigned long long sreg, pend, ahead;
+    int p_fill, w_next, used = 0;
     {
-        const unsigned long long w = my_stream[s_idx >> 4] >> (4 * (s_idx & 15)), nw = my_stream[(s_idx >> 4) + 1];
-        s_lo = (unsigned)w; s_hi = (unsigned)(w >> 32);
-        n_lo = (unsigned)nw; n_hi = (unsigned)(nw >> 32);
+        const int s_idx = is_last ? 0 : 31;               // next character: seq2[0] / seq1[31]
+        const int c0 = s_idx & 15, w0i = s_idx >> 4;
+        const unsigned long long w0 = my_stream[w0i], w1 = my_stream[w0i + 1];
+        sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
+        pend = w1 >> (4 * c0);
+        p_fill = 16 - c0;
+        ahead = my_stream[w0i + 2];
+        w_next = w0i + 3;
     }
+    auto top_up = [&]() {                                 // `used` characters consumed since the last call: refill sreg to 16
+        const int k = used;
+        used = 0;
+        const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
+        // pend's first `from_pend` characters go behind the 16 - k that are left; whatever of pend does not fit falls off the top
+        const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;
+        const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
+        sreg |= add_p | add_a;
+        const bool crossed = rem > 0 || from_pend == p_fill;                         // pend is used up: `ahead` becomes pend
+        if (crossed) {
+            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
+            p_fill = 16 - rem;
+            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;          // a band that has left the matrix keeps stepping: stay inside the stream
+            ahead = my_stream[w];
+            ++w_next;
+        } else {
+            pend = from_pend ? pend >> (4 * from_pend) : pend;
+            p_fill -= from_pend;
+        }
+    };
     auto pick_win = [&](int m, win_t if_set, win_t if_clear) -> win_t {
         if constexpr (C == 8) {
             return (win_t)pick(m, (int)if_set, (int)if_clear);
@@ -353,6 +383,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const bool right = group_first(cur[0]) + (((G - 1) * C) << 2) < group_last(cur[C - 1]);
         const int rmask = keep_opaque(right ? -1 : 0);
         pos_x -= rmask;                                   // += 1 when the band steps right
+        dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);   // (dir_word >> 1) | (right << 31)
         const int pos_y = round - (pos_x - 31);
         alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
         // neighbours of the slice in the previous round's band, re-based to this lane's share of the index
@@ -360,6 +391,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const int lo_in = pick(first_mask, kDropped, p_lo), hi_in = pick(last_mask, kDropped, p_hi);
         // sequence windows follow the band
         {
+            const unsigned s_lo = (unsigned)sreg, s_hi = (unsigned)(sreg >> 32);
             const unsigned cand = s_lo & 15u;             // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
             const unsigned a_top = (unsigned)(aw >> (4 * C - 4)), b_low = (unsigned)bw & 15u;
             // (the DPP moves are evaluated by ALL lanes before the select: inside one arm of `?:` they would run with the
@@ -373,15 +405,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             bw = pick_win(rmask, bw_r, bw);
             const int cmask = keep_opaque(~(rmask ^ last_mask));              // consume = is_last ? right : !right
             const unsigned sh_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, 4), sh_hi = s_hi >> 4;
-            s_lo = (unsigned)pick(cmask, (int)sh_lo, (int)s_lo);
-            s_hi = (unsigned)pick(cmask, (int)sh_hi, (int)s_hi);
-            s_idx -= cmask;
-            if (cmask != 0 && (s_idx & 15) == 0) {        // sixteen consumed: take the prefetched word, request the one after
-                s_lo = n_lo; s_hi = n_hi;
-                const int next_word = (s_idx >> 4) + 1;   // a band that has left the matrix keeps stepping: stay inside the stream
-                const unsigned long long nw = my_stream[next_word < kStreamWords ? next_word : kStreamWords - 1];
-                n_lo = (unsigned)nw; n_hi = (unsigned)(nw >> 32);
-            }
+            const unsigned n_lo = (unsigned)pick(cmask, (int)sh_lo, (int)s_lo);
+            const unsigned n_hi = (unsigned)pick(cmask, (int)sh_hi, (int)s_hi);
+            sreg = ((unsigned long long)n_hi << 32) | n_lo;
+            used -= cmask;
         }
         win_t z = aw ^ bw;
         z |= z >> 1;
@@ -420,6 +447,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         best = pick(imask, round_best, best);
         best_round = pick(imask, round, best_round);
         best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
+        best_top = pick(imask, pos_y, best_top);
         const int thr = (best - kXDrop > 1 ? best - kXDrop : 1) * kScale;     // :1938-1941, and "0 means dropped"
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -428,12 +456,13 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             const int below_thr = keep_opaque(cur[c] - thr) >> 31;   // (opaque difference: `(a - b) >> 31` alone becomes cmp + select)
             cur[c] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[c], (unsigned)below_thr, (unsigned)clean_mask, 0xA8);
         }
-        if (C == 8) *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 7)) = (uint16_t)(tags >> 16);
-        else        *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 7)) = tags;
-        if (is_first) stage_top[al][round & 31] = (uint16_t)pos_y;
-        if ((round & 7) == 7) flush_codes(round >> 3);
-        if ((round & 31) == 31) flush_top(round >> 5);
-        rounds = alive ? round + 1 : rounds;
+        if (C == 8) *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15)) = (uint16_t)(tags >> 16);
+        else        *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
+        if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
+            flush_codes(round >> 4);
+            top_up();
+            if ((round & 31) == 31 && real && is_first) my_dirs[(size_t)(round >> 5) * n] = dir_word;
+        }
         alive = alive && round_best != 0;                 // :1943-1946
         last_round = round;
     };
@@ -444,29 +473,32 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         if (!__any(alive)) break;
         one_round(round + 1, sp_b, sp_a);
     }
-    if ((last_round & 7) != 7) flush_codes(last_round >> 3);
-    if ((last_round & 31) != 31) flush_top(last_round >> 5);
+    if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     // .z: the best cell's band lane, and bit 8 = "code records in tag format" (cell k at bits 2k: 3 diag, 2 up, 1 left)
-    if (real && is_first) summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, rounds);
+    if (real && is_first) {
+        if ((last_round & 31) != 31) my_dirs[(size_t)(last_round >> 5) * n] = dir_word >> (31 - (last_round & 31));
+        summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
+    }
 }
 
 // Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
 // 64 consecutive rounds of (code words, band row) each, fetched with coalesced loads one block ahead of the walker, and
-// the walker picks its round with v_readlane.  Two walks: the first counts the steps, the second writes the positions
+// the walker picks its round with v_readlane.  The band row of a round is rebuilt from the move bits: row of the top cell
+// = round - (right moves up to and including the round) -- a popcount over the block's 64 bits below the lane.  Two walks: the first counts the steps, the second writes the positions
 // at their final (ascending) index, 64 at a time.
 __global__ void __launch_bounds__(64)
-sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
+sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
                     uint32_t cap, uint32_t *__restrict__ lengths)
 {
     const uint32_t a = blockIdx.x;
     const int lane = threadIdx.x;
     const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride;
-    const uint16_t *my_top = top_y + (size_t)a * kTopStride;
+    const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]
     int4 sum = summary[a];
     const bool tag_format = (sum.z & kTagFormat) != 0;
     sum.z &= 31;
-    const int y0 = (int)my_top[sum.y] + 31 - sum.z;
+    const int y0 = sum.w + 31 - sum.z;                    // .w = row of the band's top cell in the best round
     const int x0 = sum.y - y0;
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
 
@@ -477,16 +509,22 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     for (int pass = one_walk ? 1 : 0; pass < 2; ++pass) {
         int y = y0, x = x0;
         int base = ((y + x) >> 6) << 6;                   // lanes hold rounds base .. base+63 (cur) and base-64 .. base-1 (nxt)
-        auto fetch = [&](int b, uint2 &cw, int &tw) {
+        const unsigned long long below_me = (2ull << lane) - 1;               // the block's rounds up to and including this lane's
+        auto fetch = [&](int b, uint2 &cw, unsigned long long &bits) {       // codes of round b + lane; move bits of rounds b .. b + 63
             const int r = b + lane;
             const bool ok = b >= 0 && r < kMaxRound;
             cw = ok ? my_codes[r] : make_uint2(0, 0);
-            tw = ok ? (int)my_top[r] : 0;
+            const int w = b >> 5;                          // b is a multiple of 64
+            const unsigned lo = b >= 0 ? my_dirs[(size_t)w * n] : 0u, hi = (b >= 0 && w + 1 < kDirWords) ? my_dirs[(size_t)(w + 1) * n] : 0u;
+            bits = ((unsigned long long)hi << 32) | lo;
         };
         uint2 cw, nw;
-        int tw, nt;
-        fetch(base, cw, tw);
-        fetch(base - 64, nw, nt);
+        unsigned long long cbits, nbits;
+        fetch(base, cw, cbits);
+        fetch(base - 64, nw, nbits);
+        // right moves in the rounds before `base`: from the best round's band row, (best round - its right moves)
+        int rights_before = (sum.y - sum.w) - __popcll(cbits & ((2ull << (sum.y - base)) - 1));
+        int tw = (base + lane) - (rights_before + __popcll(cbits & below_me));
         uint32_t count = 0;                               // positions emitted so far (descending order)
         int by = 0, bx = 0;                               // this lane's slot of the 64-position output buffer
         bool more = true;
@@ -500,8 +538,10 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
                 const int r = y + x;
                 if (r < base) {                           // walked off the block: take the prefetched one, prefetch the next
                     base -= 64;
-                    cw = nw; tw = nt;
-                    fetch(base - 64, nw, nt);
+                    cw = nw; cbits = nbits;
+                    rights_before -= __popcll(cbits);
+                    tw = (base + lane) - (rights_before + __popcll(cbits & below_me));
+                    fetch(base - 64, nw, nbits);
                 }
                 const int idx = __builtin_amdgcn_readfirstlane(r - base);
                 const unsigned lo = __builtin_amdgcn_readlane(cw.x, idx), hi = __builtin_amdgcn_readlane(cw.y, idx);
@@ -551,23 +591,23 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
 constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
 
 __global__ void __launch_bounds__(64)
-sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ top_y,
+sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
                     int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
 {
     __shared__ uint4 line_codes[64][4 + 1];               // [lane][16-byte quarter of the line], padded
-    __shared__ uint4 line_top[64][4 + 1];
     const int lane = threadIdx.x;
     const uint32_t a0 = blockIdx.x * 64 + threadIdx.x;
     const bool real = a0 < n;
     const uint32_t a = real ? a0 : n - 1;                 // tail lanes shadow the last alignment and store nothing
     const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
-    const uint4 *my_top = reinterpret_cast<const uint4 *>(top_y + (size_t)a * kTopStride);
+    const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
     unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     int4 sum = summary[a];
     const bool tag_format = (sum.z & kTagFormat) != 0;
     sum.z &= 31;
-    int y = (int)top_y[(size_t)a * kTopStride + sum.y] + 31 - sum.z;
+    int top = sum.w;                                      // row of the band's top cell in the walk's current round
+    int y = top + 31 - sum.z;
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
     int wmax = sum.y >> 3;
@@ -579,29 +619,34 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
     uint32_t steps = 0;
     unsigned acc_lo = 0, acc_hi = 0;                      // the last (steps & 31) moves, 2 bits each
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        line_codes[lane][q] = my_codes[4 * wmax + q];
-        line_top[lane][q] = my_top[4 * (wmax >> 2) + q];
-    }
+    for (int q = 0; q < 4; ++q) line_codes[lane][q] = my_codes[4 * wmax + q];
+    // move bits of the 32-round block the current window lies in (d_hi) and of the block below it (d_lo): a diagonal step
+    // from the first round of a block needs the move of the round before it
+    int blk = wmax >> 2;
+    unsigned d_hi = my_dirs[(size_t)blk * n], d_lo = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;
     for (int w = wmax; w >= 0; --w) {
-        // request the lines of window w - 1 now; they are needed only after window w has been walked
+        // request the line of window w - 1 now; it is needed only after window w has been walked
         // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
         const int wp = w > 0 ? w - 1 : 0;
-        const bool top_changes = (w & 3) == 0;            // window w - 1 lies in the previous 32-round line of band rows
+        const bool blk_changes = (w & 3) == 0 && w > 0;   // window w - 1 lies in the 32-round block below
         const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
-        uint4 nt0 = make_uint4(0, 0, 0, 0), nt1 = nt0, nt2 = nt0, nt3 = nt0;
-        if (top_changes) {
-            const uint4 *tp = my_top + 4 * (wp >> 2);
-            nt0 = tp[0]; nt1 = tp[1]; nt2 = tp[2]; nt3 = tp[3];
-        }
+        unsigned nd = 0;
+        if (blk_changes && blk >= 2) nd = my_dirs[(size_t)(blk - 2) * n];
         while (walking && ((y + x) >> 3) == w) {
             const int r = y + x;
             const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
-            const int top = (int)reinterpret_cast<const uint16_t *>(&line_top[lane][0])[r & 31];
             const int bl = 31 - (y - top);
             const unsigned code = decode_code(cw, bl, tag_format);                   // never 0 on a live path
-            y -= (code == 1 || code == 2) ? 1 : 0;        // 1 diag, 2 up: one row back
-            x -= (code == 1 || code == 3) ? 1 : 0;        // 1 diag, 3 left: one column back
+            const int dy = (code == 1 || code == 2) ? 1 : 0;                         // 1 diag, 2 up: one row back
+            const int dx = (code == 1 || code == 3) ? 1 : 0;                         // 1 diag, 3 left: one column back
+            // band row of the round the walk lands in: every round that was a DOWN move lowers it by one going back
+            const int r1 = r - 1;
+            const unsigned right0 = ((r >> 5) == blk ? d_hi : d_lo) >> (r & 31) & 1u;
+            const unsigned right1 = ((r1 >> 5) == blk ? d_hi : d_lo) >> (r1 & 31) & 1u;
+            top -= (dy | dx) ? 1 - (int)right0 : 0;
+            top -= (dy & dx) ? 1 - (int)right1 : 0;
+            y -= dy;
+            x -= dx;
             const unsigned sh = 2 * (steps & 15u);
             if (steps & 16u) acc_hi |= code << sh; else acc_lo |= code << sh;
             ++steps;
@@ -612,8 +657,10 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint16
             walking = code != 0 && (y | x) != 0;
         }
         line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
-        if (top_changes) {
-            line_top[lane][0] = nt0; line_top[lane][1] = nt1; line_top[lane][2] = nt2; line_top[lane][3] = nt3;
+        if (blk_changes) {
+            --blk;
+            d_hi = d_lo;
+            d_lo = nd;
         }
     }
     if (real) {
@@ -664,7 +711,7 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
 namespace {
 inline size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
 inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeStride * sizeof(uint2)); }
-inline size_t top_bytes(size_t n) { return round16(n * (size_t)kTopStride * sizeof(uint16_t)); }
+inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * sizeof(uint32_t)); }
 }  // namespace
 
 inline size_t streams_bytes(size_t n) { return round16(n * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }
@@ -672,7 +719,7 @@ inline size_t moves_bytes(size_t n) { return round16(n * (size_t)kMoveWords * si
 
 size_t semiglobal_workspace_bytes(size_t n)
 {
-    return codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
+    return codes_bytes(n) + dirs_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
 }
 
 namespace {
@@ -727,9 +774,9 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     if (n == 0) return hipSuccess;
     char *ws = static_cast<char *>(d_workspace);
     uint32_t *codes = reinterpret_cast<uint32_t *>(ws);
-    uint16_t *top = reinterpret_cast<uint16_t *>(ws + codes_bytes(n));
-    int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + top_bytes(n));
-    unsigned long long *streams = reinterpret_cast<unsigned long long *>(ws + codes_bytes(n) + top_bytes(n) + round16(n * sizeof(int4)));
+    uint32_t *top = reinterpret_cast<uint32_t *>(ws + codes_bytes(n));          // the band's move bits (kDirWords x n)
+    int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + dirs_bytes(n));
+    unsigned long long *streams = reinterpret_cast<unsigned long long *>(ws + codes_bytes(n) + dirs_bytes(n) + round16(n * sizeof(int4)));
     unsigned long long *moves = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)

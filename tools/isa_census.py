@@ -178,14 +178,31 @@ def census(instrs, marker_op=None):
         t["issue_cycles_measured_rates"] = round(t["issue_cycles_measured_rates"], 2)
         return t
 
+    conditional = []
     if main:
         a, b = main
-        inside = instrs[a:b + 1]
+        # Blocks inside the main loop that a forward SCALAR-condition branch jumps over run only on some iterations (a flush
+        # every 16th round ...): they are tallied apart, and the caller says how often they run.  (Blocks under an EXEC mask,
+        # s_cbranch_execz, are per-lane predication and count as always executed.)
+        skip = set()
+        for k in range(a, b + 1):
+            ins = instrs[k]
+            # (scc = a scalar compare such as `(round & 15) == 15`; vcc branches come from wavefront votes like __any(alive),
+            # which guard the loop's exit, not an occasional block)
+            if ins["op"] in ("s_cbranch_scc0", "s_cbranch_scc1") and ins["target_off"] is not None:
+                tgt = start + ins["target_off"]
+                if ins["addr"] < tgt <= instrs[b]["addr"]:
+                    span = [i for i in range(k + 1, b + 1) if instrs[i]["addr"] < tgt]
+                    if len(span) >= 8:
+                        skip.update(span)
+        inside = [instrs[i] for i in range(a, b + 1) if i not in skip]
+        conditional = [instrs[i] for i in sorted(skip)]
         outside = instrs[:a] + instrs[b + 1:]
     else:
         inside, outside = [], instrs
     text = "\n".join("%s %s" % (i["op"], re.sub(r"\s+", " ", i["args"])) for i in instrs)
-    return {"main_loop": tally(inside), "outside_main_loop": tally(outside), "other_loops": max(0, len(loops) - 1),
+    return {"main_loop": tally(inside), "main_loop_conditional": tally(conditional), "outside_main_loop": tally(outside),
+            "other_loops": max(0, len(loops) - 1),
             "code_sha256": hashlib.sha256(text.encode()).hexdigest()[:16], "code_bytes": max(i["addr"] for i in instrs) - start + 4}
 
 
@@ -207,14 +224,15 @@ def census_for(kernel_regex, lib_path=DEFAULT_LIB, marker_op=None):
     return out
 
 
-def issue_cycles_per_wave(c, main_loop_trips, rates="ideal"):
-    """VALU issue cycles one wavefront needs: everything outside the main loop once + the loop body x trips."""
+def issue_cycles_per_wave(c, main_loop_trips, rates="ideal", conditional_share=1.0):
+    """VALU issue cycles one wavefront needs: everything outside the main loop once + the loop body x trips, the loop's
+    conditional blocks (see census) weighted by the share of trips they run on."""
     key = "issue_cycles_ideal" if rates == "ideal" else "issue_cycles_measured_rates"
-    return c["outside_main_loop"][key] + main_loop_trips * c["main_loop"][key]
+    return c["outside_main_loop"][key] + main_loop_trips * (c["main_loop"][key] + conditional_share * c["main_loop_conditional"][key])
 
 
-def valu_instructions_per_wave(c, main_loop_trips):
-    return c["outside_main_loop"]["valu"] + main_loop_trips * c["main_loop"]["valu"]
+def valu_instructions_per_wave(c, main_loop_trips, conditional_share=1.0):
+    return c["outside_main_loop"]["valu"] + main_loop_trips * (c["main_loop"]["valu"] + conditional_share * c["main_loop_conditional"]["valu"])
 
 
 def main():
@@ -239,6 +257,10 @@ def main():
         print("  main loop : %4d instr, %4d VALU, %7.1f issue cycles per iteration (ideal 2/4/8), %7.1f at measured rates; %s"
               % (ml["instructions"], ml["valu"], ml["issue_cycles_ideal"], ml["issue_cycles_measured_rates"], ml["by_class"]))
         print("              VALU by op: %s" % dict(sorted(ml["by_op"].items(), key=lambda kv: -kv[1])))
+        cl = c["main_loop_conditional"]
+        if cl["instructions"]:
+            print("  + blocks under a scalar condition (not every iteration): %4d instr, %4d VALU, %7.1f issue cycles (ideal)"
+                  % (cl["instructions"], cl["valu"], cl["issue_cycles_ideal"]))
         print("  elsewhere : %4d instr, %4d VALU, %7.1f issue cycles (ideal), unmeasured VALU %d; other loops %d"
               % (ol["instructions"], ol["valu"], ol["issue_cycles_ideal"], ol["unmeasured_valu"], c["other_loops"]))
     if args.json:
