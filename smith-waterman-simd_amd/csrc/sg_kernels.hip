@@ -31,8 +31,8 @@ constexpr int kCodeStride = (kMaxRound + 15) & ~15;      // uint2 entries (8 B):
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
 constexpr int kDirWords = kMaxRound / 32 + 1;
 // which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
-constexpr size_t kSplit4MinBatch = 6144;         // band over 4 (later 2) lanes from here on
-constexpr size_t kLaneTracebackMinBatch = 3072;  // one lane per walk (+ expand kernel) from here on
+constexpr size_t kSplit4MinBatch = 4096;         // band over 4 (later 2) lanes from here on
+constexpr size_t kLaneTracebackMinBatch = 2048;  // one lane per walk (+ expand kernel) from here on
 
 // summary[a].z = band lane of the best cell | kTagFormat when the alignment's code records are in the split sweep's tag
 // format (64 bits per round, band cell k at bits 2k..2k+1: 3 diagonal, 2 up, 1 left) instead of the half-wavefront
@@ -99,10 +99,10 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0;
     bool alive = true;
     unsigned dir_word = 0;                                // move bits of the current 32 rounds: round r enters at bit 31, ends at bit r & 31
-    int last_round = 0;
     if (writer) my_codes[0] = make_uint2(0, 0);
 
-    for (int round = 1; round < kMaxRound; ++round) {
+    int round = 1;
+    for (; round < kMaxRound; ++round) {
         if (!__any(alive)) break;
         // direction of each alignment's band: lane 0 against lane 31 (source.cpp:1895)
         const bool right_a = __builtin_amdgcn_readlane(cur, 0) < __builtin_amdgcn_readlane(cur, 31);
@@ -116,7 +116,9 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         hor = nh;
         ver = nv;
         pos_x += right ? 1 : 0;
-        dir_word = (dir_word >> 1) | (right ? 0x80000000u : 0u);
+        // one VALU instruction (per lane, off the round's dependency chain); on the scalar unit it costs six, and this
+        // kernel runs one wavefront per SIMD or less, where every instruction of any kind costs ~5 cycles
+        dir_word = __builtin_amdgcn_alignbit(right ? 0xFFFFFFFFu : 0u, dir_word, 1);
         const int pos_y = round - (pos_x - 31);
         const bool inside = pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;      // :1903, :1913: checked before the round is stored
         alive = alive && inside;
@@ -153,13 +155,16 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
             my_codes[round] = second ? make_uint2((unsigned)(bit0 >> 32), (unsigned)(bit1 >> 32))
                                      : make_uint2((unsigned)bit0, (unsigned)bit1);
         }
-        if ((round & 31) == 31 && writer) my_dirs[(size_t)(round >> 5) * n] = dir_word;
+        if ((round & 31) == 31) {                         // (a running pointer: `(round >> 5) * n` would be recomputed every round)
+            if (writer) *my_dirs = dir_word;
+            my_dirs += n;
+        }
         cur = alive ? v : cur;
         alive = alive && round_best != 0;                 // :1943-1946
-        last_round = round;
     }
+    const int last_round = round - 1;                     // the last round that ran
     if (writer) {
-        if ((last_round & 31) != 31) my_dirs[(size_t)(last_round >> 5) * n] = dir_word >> (31 - (last_round & 31));
+        if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
         summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
     }
 }
@@ -461,7 +466,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
             flush_codes(round >> 4);
             top_up();
-            if ((round & 31) == 31 && real && is_first) my_dirs[(size_t)(round >> 5) * n] = dir_word;
+            if ((round & 31) == 31) {
+                if (real && is_first) *my_dirs = dir_word;
+                my_dirs += n;
+            }
         }
         alive = alive && round_best != 0;                 // :1943-1946
         last_round = round;
@@ -476,7 +484,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     // .z: the best cell's band lane, and bit 8 = "code records in tag format" (cell k at bits 2k: 3 diag, 2 up, 1 left)
     if (real && is_first) {
-        if ((last_round & 31) != 31) my_dirs[(size_t)(last_round >> 5) * n] = dir_word >> (31 - (last_round & 31));
+        if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
         summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
     }
 }
@@ -606,8 +614,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     int4 sum = summary[a];
     const bool tag_format = (sum.z & kTagFormat) != 0;
     sum.z &= 31;
-    int top = sum.w;                                      // row of the band's top cell in the walk's current round
-    int y = top + 31 - sum.z;
+    int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
     int wmax = sum.y >> 3;
@@ -620,10 +627,18 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     unsigned acc_lo = 0, acc_hi = 0;                      // the last (steps & 31) moves, 2 bits each
 #pragma unroll
     for (int q = 0; q < 4; ++q) line_codes[lane][q] = my_codes[4 * wmax + q];
-    // move bits of the 32-round block the current window lies in (d_hi) and of the block below it (d_lo): a diagonal step
-    // from the first round of a block needs the move of the round before it
+    // Band row of a round r = r - (right moves up to and including r) = r - (rights_before + popcount of the block's move
+    // bits up to r): no state carried from step to step, and a shorter dependency chain than an LDS lookup.
+    // d_blk = move bits of the 32-round block the current window lies in; rights_before = right moves before that block,
+    // known from the best round's band row when the wavefront reaches the block this walk starts in.
     int blk = wmax >> 2;
-    unsigned d_hi = my_dirs[(size_t)blk * n], d_lo = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;
+    const int start_blk = sum.y >> 5;
+    unsigned d_blk = my_dirs[(size_t)blk * n];
+    int rights_before = 0;
+    auto enter_block = [&]() {
+        if (blk == start_blk) rights_before = (sum.y - sum.w) - __popc(d_blk & ((2u << (sum.y & 31)) - 1u));
+    };
+    enter_block();
     for (int w = wmax; w >= 0; --w) {
         // request the line of window w - 1 now; it is needed only after window w has been walked
         // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
@@ -631,22 +646,15 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         const bool blk_changes = (w & 3) == 0 && w > 0;   // window w - 1 lies in the 32-round block below
         const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
         unsigned nd = 0;
-        if (blk_changes && blk >= 2) nd = my_dirs[(size_t)(blk - 2) * n];
+        if (blk_changes) nd = my_dirs[(size_t)(blk - 1) * n];
         while (walking && ((y + x) >> 3) == w) {
             const int r = y + x;
             const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
+            const int top = r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
             const int bl = 31 - (y - top);
             const unsigned code = decode_code(cw, bl, tag_format);                   // never 0 on a live path
-            const int dy = (code == 1 || code == 2) ? 1 : 0;                         // 1 diag, 2 up: one row back
-            const int dx = (code == 1 || code == 3) ? 1 : 0;                         // 1 diag, 3 left: one column back
-            // band row of the round the walk lands in: every round that was a DOWN move lowers it by one going back
-            const int r1 = r - 1;
-            const unsigned right0 = ((r >> 5) == blk ? d_hi : d_lo) >> (r & 31) & 1u;
-            const unsigned right1 = ((r1 >> 5) == blk ? d_hi : d_lo) >> (r1 & 31) & 1u;
-            top -= (dy | dx) ? 1 - (int)right0 : 0;
-            top -= (dy & dx) ? 1 - (int)right1 : 0;
-            y -= dy;
-            x -= dx;
+            y -= (code == 1 || code == 2) ? 1 : 0;        // 1 diag, 2 up: one row back
+            x -= (code == 1 || code == 3) ? 1 : 0;        // 1 diag, 3 left: one column back
             const unsigned sh = 2 * (steps & 15u);
             if (steps & 16u) acc_hi |= code << sh; else acc_lo |= code << sh;
             ++steps;
@@ -659,8 +667,9 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
         if (blk_changes) {
             --blk;
-            d_hi = d_lo;
-            d_lo = nd;
+            d_blk = nd;
+            rights_before -= (int)__popc(d_blk);
+            enter_block();
         }
     }
     if (real) {
@@ -743,9 +752,12 @@ int choose_sweep(size_t n, int compute_units)
         // per started wavefront-per-SIMD, so the model carries over to other CU counts through w4 / w2)
         const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
         const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds);
-        const double t4 = w4 <= 1 ? 16.2 : w4 == 2 ? 23.5 : w4 == 3 ? 31.7 : 5.7 + 8.57 * w4;
-        const double t2 = w2 <= 2 ? 38.0 : 6.6 + 15.45 * w2;        // (W = 3 stays the fastest 2-lane build beyond 3 per SIMD)
-        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 <= 2 ? 2 : 3);
+        // (profiles/r02_sg_kernel_matrix.txt)
+        const double t4 = w4 <= 1 ? 12.9 : w4 == 2 ? 19.2 : w4 == 3 ? 27.0 : w4 == 4 ? 34.3 : 4.5 + 7.45 * w4;
+        const double t2 = w2 <= 1 ? 19.6 : w2 == 2 ? 30.9 : w2 == 3 ? 43.7 : 5.4 + 12.85 * w2;
+        // the build whose scheduling target equals the wavefronts a SIMD actually gets wins (W = 3 stays the fastest
+        // 2-lane build beyond 3 per SIMD)
+        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 < 1 ? 1 : w2 > 3 ? 3 : w2);
     }
     return sweep;
 }
