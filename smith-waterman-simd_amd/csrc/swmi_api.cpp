@@ -150,7 +150,12 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
 {
     std::lock_guard<std::mutex> lock(ctx.mu);
     const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
-    const size_t chunk = n < kChunkPairs ? n : kChunkPairs;
+    size_t chunk_cap = kChunkPairs;
+    if (const char *env = getenv("SWMI_HOST_CHUNK")) {     // experiment knob: pairs per pipeline granule
+        const long long v = atoll(env);
+        if (v >= 1024 && size_t(v) <= kChunkPairs) chunk_cap = size_t(v);
+    }
+    const size_t chunk = n < chunk_cap ? n : chunk_cap;
     SmRows rows;
     const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, chunk);
     for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
