@@ -670,6 +670,23 @@ def single_gpu(args, swmi, np, torch, local_rank):
                                 "kernel_ms": r111["kernel_ms"], "frac": r111.get("frac"), "steps": 20,
                                 "gpu_mismatches": int((want111 != scores[:4096].cpu().numpy()).sum()), "checked_against": "%s, first 4096 pairs" % who,
                                 "workload": "SURVEY 8f N2: sm +1/-1, gap 1 (SmithWaterman_8bit111simd, source.cpp:1105-1225) on the general kernel"}
+    # ... and the one alternative cell that ties on paper for these parameters -- 16-bit state, three full-rate v_max_i16
+    # instead of v_max3_i32 + the running max (schedule flags 1 | 2: h = max(max(left, up) -sat gap, dot4)) -- measured
+    # beside it: the negative result of DESIGN.md section 5.1
+    swmi.set_schedule(args.lanes, 3)
+    try:
+        ms111_16 = time_launches(torch, stream, lambda: swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm111, 1, scores.data_ptr(),
+                                                                               stream.cuda_stream), 20, 5)
+    finally:
+        swmi.set_schedule(args.lanes, 0)
+    r111_16 = sw128_roofline(swmi, P, lanes, 3, "pairs", ms111_16, 1, -1, 1)
+    rows["fixed_111_scorer_16bit_cell"] = {"value": round(P / (ms111_16 * 1e-3), 1), "unit": "alignments/s", "kernel": r111_16.get("kernel"),
+                                           "kernel_ms": r111_16["kernel_ms"], "frac": r111_16.get("frac"), "steps": 20,
+                                           "gpu_mismatches": int((want111 != scores[:4096].cpu().numpy()).sum()),
+                                           "checked_against": "%s, first 4096 pairs" % who,
+                                           "speedup_over_general_kernel": round(ms111 / ms111_16, 3),
+                                           "workload": "the same with the 16-bit cell body (swmi_set_schedule flags 1|2): the specialisation "
+                                                       "experiment for row N2; not faster, so the general kernel stays"}
     del d1, d2, scores
     torch.cuda.empty_cache()
     rows["banded_affine_1024"] = row_summary(bench_banded(args, swmi, np, torch, local_rank, steps=10, warmup=3))
