@@ -27,6 +27,25 @@ inline int SmithWaterman_mi355x(const std::array<uint8_t, 128> &seq1, const std:
 
 namespace swmi {
 
+// The reference's 1M-call loop (source.cpp:3074-3082) over arrays of pairs, on every GPU the library is bound to:
+// scores[k] == SmithWaterman(seq1s[k], seq2s[k], score_matrix, gap_penalty).  std::array<uint8_t,128> has no padding, so a
+// vector of them IS the concatenated layout the C ABI takes.  With swmi_init(device) it runs on that one GPU, with
+// swmi_init_all(G) the batch is cut into G contiguous shards, one host thread and stream set per GPU (swmi_score_batch_multi).
+inline std::vector<int32_t> SmithWaterman_mi355x_batch(const std::vector<std::array<uint8_t, 128>> &seq1s,
+                                                       const std::vector<std::array<uint8_t, 128>> &seq2s,
+                                                       const std::array<int8_t, 16> &score_matrix, const int8_t gap_penalty)
+{
+    static_assert(sizeof(std::array<uint8_t, 128>) == 128, "std::array<uint8_t,128> must be 128 contiguous bytes");
+    if (seq1s.size() != seq2s.size()) throw std::invalid_argument("SmithWaterman_mi355x_batch: seq1s and seq2s differ in length");
+    std::vector<int32_t> scores(seq1s.size());
+    const uint8_t *a = seq1s.empty() ? nullptr : seq1s[0].data(), *b = seq2s.empty() ? nullptr : seq2s[0].data();
+    const int rc = swmi_num_gpus() > 1
+                       ? swmi_score_batch_multi(a, b, seq1s.size(), score_matrix.data(), gap_penalty, scores.data())
+                       : swmi_score_batch(a, b, seq1s.size(), score_matrix.data(), gap_penalty, scores.data());
+    if (rc != SWMI_OK) throw std::runtime_error(std::string("SmithWaterman_mi355x_batch: ") + swmi_last_error());
+    return scores;
+}
+
 // Batches per-pair calls: submit() has the reference's argument list and returns a ticket; scores() drains.
 class PairQueue {
 public:

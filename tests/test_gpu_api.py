@@ -145,6 +145,7 @@ def test_cpp_compat_header_and_pair_queue(gpu, golden, tmp_path):
     assert len(rows) == n
     assert [r[0] for r in rows] == list(f["scores"][0][:n])
     assert [r[1] for r in rows] == list(f["scores"][0][:n])
+    assert [r[2] for r in rows] == list(f["scores"][0][:n])          # the whole-array overload (and, inside the program, its two-context split)
 
 
 def test_automatic_schedule_follows_the_batch_size(gpu, oracle):
