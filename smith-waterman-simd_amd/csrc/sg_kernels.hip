@@ -176,20 +176,28 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
 // pre-pass rewrites both sequences of every alignment as streams of 4-bit fields, 16 per 64-bit word: the base (0..3), and
 // past the end of the sequence the pad the reference appends (source.cpp:1861-1873) -- 8 for seq1, 4 for seq2, so that a
 // pad never equals a base or the other pad.  The sweep then needs no index arithmetic, range checks or byte extraction:
-// next character = low field of a 64-bit shift register, refilled every 16 moves with one prefetched load.
+// next character = low field of a 64-bit shift register, topped up every 16 rounds from prefetched words.
+// Layout: the streams of the A alignments one sweep wavefront owns are interleaved word by word,
+//     streams[(block * kStreamWords + word) * 2A + alignment_in_block * 2 + {0: seq1, 1: seq2}]
+// because the lanes of a wavefront ask for (nearly) the same word index at the same time: their 8-byte loads then fall
+// into the same few 64-byte lines (with one stream after the other per alignment, every 8-byte load pulled in a line of
+// its own and each line was fetched up to eight times: 10 GB of fetches for 1.1 GB of streams at 65536 alignments).
 constexpr int kStreamWords = (kLen + 128) / 16;          // 16 fields per word; 128 fields of pad cover every read-ahead
 
 __global__ void __launch_bounds__(256)
 sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
-                       unsigned long long *__restrict__ streams)
+                       unsigned long long *__restrict__ streams, uint32_t per_block /* A: alignments per sweep wavefront */)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;              // one thread per output word
-    const size_t per_alignment = 2 * (size_t)kStreamWords;
-    if (t >= (size_t)n * per_alignment) return;
-    const uint32_t a = (uint32_t)(t / per_alignment);
-    const uint32_t w = (uint32_t)(t % per_alignment);
-    const bool second = w >= (uint32_t)kStreamWords;                      // words [0, kStreamWords) = seq1, then seq2
-    const uint32_t j = second ? w - kStreamWords : w;                     // characters 16 j .. 16 j + 15
+    const uint32_t slots = 2 * per_block;
+    const size_t n_blocks = ((size_t)n + per_block - 1) / per_block;
+    if (t >= n_blocks * kStreamWords * slots) return;
+    const uint32_t slot = (uint32_t)(t % slots);
+    const size_t rest = t / slots;
+    const uint32_t j = (uint32_t)(rest % kStreamWords);                   // characters 16 j .. 16 j + 15
+    const uint32_t a_full = (uint32_t)(rest / kStreamWords) * per_block + (slot >> 1);
+    const uint32_t a = a_full < n ? a_full : n - 1;                       // a ragged last block shadows the last alignment
+    const bool second = slot & 1u;                                        // 0: seq1, 1: seq2
     unsigned long long out;
     if (j < (uint32_t)(kLen / 16)) {
         const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * j);
@@ -261,8 +269,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const uint32_t a0 = block_first + al;
     const bool real = a0 < n;
     const uint32_t a = real ? a0 : n - 1;
-    const unsigned long long *stream_a = streams + (size_t)a * (2 * kStreamWords);
-    const unsigned long long *stream_b = stream_a + kStreamWords;
+    // word w of this alignment's seq1 / seq2 stream: stream_x[w * kStreamStride] (interleaved layout, see sg_pack_streams_kernel)
+    constexpr size_t kStreamStride = 2 * A;
+    const unsigned long long *stream_a = streams + (size_t)blockIdx.x * kStreamWords * kStreamStride + 2 * al;
+    const unsigned long long *stream_b = stream_a + 1;
     // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
     uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 4);
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
@@ -316,7 +326,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
     win_t aw = 0, bw = 0;
     {
-        const unsigned long long w0 = stream_a[0], w1 = stream_a[1];         // seq1[0..31]
+        const unsigned long long w0 = stream_a[0], w1 = stream_a[kStreamStride];   // seq1[0..31]
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int i1 = 30 - (g * C + c);                                  // differs per lane: shifts, not indexing
@@ -345,11 +355,11 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     {
         const int s_idx = is_last ? 0 : 31;               // next character: seq2[0] / seq1[31]
         const int c0 = s_idx & 15, w0i = s_idx >> 4;
-        const unsigned long long w0 = my_stream[w0i], w1 = my_stream[w0i + 1];
+        const unsigned long long w0 = my_stream[w0i * kStreamStride], w1 = my_stream[(w0i + 1) * kStreamStride];
         sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
         pend = w1 >> (4 * c0);
         p_fill = 16 - c0;
-        ahead = my_stream[w0i + 2];
+        ahead = my_stream[(w0i + 2) * kStreamStride];
         w_next = w0i + 3;
     }
     auto top_up = [&]() {                                 // `used` characters consumed since the last call: refill sreg to 16
@@ -365,7 +375,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
             p_fill = 16 - rem;
             const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;          // a band that has left the matrix keeps stepping: stay inside the stream
-            ahead = my_stream[w];
+            ahead = my_stream[(size_t)w * kStreamStride];
             ++w_next;
         } else {
             pend = from_pend ? pend >> (4 * from_pend) : pend;
@@ -723,7 +733,7 @@ inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeStride * s
 inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * sizeof(uint32_t)); }
 }  // namespace
 
-inline size_t streams_bytes(size_t n) { return round16(n * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }
+inline size_t streams_bytes(size_t n) { return round16(((n + 31) / 32 * 32) * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }   // whole blocks of 32 / 16
 inline size_t moves_bytes(size_t n) { return round16(n * (size_t)kMoveWords * sizeof(unsigned long long)); }
 
 size_t semiglobal_workspace_bytes(size_t n)
@@ -794,9 +804,10 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     const int sweep = choose_sweep(n, compute_units);
     if (sweep != 0 && sweep < 100) {
-        const size_t words = n * 2 * (size_t)kStreamWords;
+        const uint32_t per_block = sweep / 10 == 4 ? 16 : 32;               // alignments per sweep wavefront: 64 / G
+        const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
-                           (uint32_t)n, streams);
+                           (uint32_t)n, streams, per_block);
         const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32));
 #define SWMI_SG_LAUNCH(G, W, GRID) \
     hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
