@@ -17,6 +17,7 @@ namespace host {
 
 namespace {
 thread_local char t_error[512] = "";
+thread_local int t_status = SWMI_OK;               // code of the last fail() on this thread
 thread_local int t_gpu = 0;                        // context index this thread addresses (swmi_use_gpu)
 std::vector<std::unique_ptr<Context>> g_ctxs;      // written only under g_init_mu, by swmi_init* / swmi_shutdown
 std::mutex g_init_mu;
@@ -31,8 +32,11 @@ int fail(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(t_error, sizeof t_error, fmt, ap);
     va_end(ap);
+    t_status = code;
     return code;
 }
+
+int last_status() { return t_status; }
 
 std::mutex &init_mutex() { return g_init_mu; }
 int num_contexts() { return (int)g_ctxs.size(); }
@@ -416,7 +420,7 @@ int swmi_get_device_info(swmi_device_info *info)
 {
     if (!info) return fail(SWMI_ERR_INVALID_ARGUMENT, "info is NULL");
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     memset(info, 0, sizeof *info);
     info->device = ctx->device;
     info->compute_units = ctx->prop.multiProcessorCount;
@@ -436,7 +440,7 @@ int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, const
     if (n == 0) return SWMI_OK;
     if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     if (n <= kPinPairs) {               // the per-pair call and its small relatives: no copies, one launch, one wait
         std::lock_guard<std::mutex> lock(ctx->mu);
         uint8_t *h1 = ctx->pin, *h2 = ctx->pin + kPinPairs * kSeq;
@@ -470,7 +474,7 @@ int swmi_score_one_vs_many(const uint8_t *seq1s, size_t n_seq1, const uint8_t se
     if (n_seq1 == 0) return SWMI_OK;
     if (!seq1s || !seq2 || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seq1 = %zu", n_seq1);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     return score_host_batch(*ctx, seq1s, seq2, n_seq1, score_matrix, gap_penalty, scores, false, true);
 }
 
@@ -484,7 +488,7 @@ int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, const void
     if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2) | reinterpret_cast<uintptr_t>(d_scores)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     SmRows rows;
     const LaunchConfig cfg = make_config(*ctx, score_matrix, gap_penalty, &rows, n_seq1);
     for (size_t off = 0; off < n_seq1; off += kMaxLaunchPairs) {
@@ -504,7 +508,7 @@ int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_pa
     if (n == 0) return SWMI_OK;
     if (!seq1s_packed || !seq2s_packed || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     return score_host_batch(*ctx, seq1s_packed, seq2s_packed, n, score_matrix, gap_penalty, scores, true, false);
 }
 
@@ -518,7 +522,7 @@ static int device_entry(const void *d1, const void *d2, size_t n, const int8_t *
     if ((reinterpret_cast<uintptr_t>(d1) | reinterpret_cast<uintptr_t>(d2) | reinterpret_cast<uintptr_t>(d_out)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
     Context *ctx = current();           // makes the context's device current: the launch must not land on whatever
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;   // device the calling thread happened to have selected
+    if (!ctx) return last_status();   // device the calling thread happened to have selected
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     return launch_device(*ctx, d1, d2, n, sm, gap, d_out, st, packed);
 }
@@ -566,7 +570,7 @@ int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, si
     if (n == 0) return SWMI_OK;
     if (!d_seq1s || !d_seq2s || !d_scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     return banded_device(*ctx, d_seq1s, d_seq2s, n, len, score_matrix, gap_open, gap_extend, d_scores, static_cast<hipStream_t>(stream));
 }
 
@@ -578,7 +582,7 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
     if (n == 0) return SWMI_OK;
     if (!seq1s || !seq2s || !scores) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
     // the slot buffers are sized in 128-byte pairs: a len-mer pair occupies ceil(len / 128) of them
     const size_t per = (size_t(len) + kSeq - 1) / kSeq;
@@ -621,7 +625,7 @@ static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n,
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned (the kernels use 16-byte loads and 8-byte stores)");
     if (n > (size_t(1) << 18)) return fail(SWMI_ERR_INVALID_ARGUMENT, "at most 2^18 alignments per call (got %zu)", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     hipStream_t st = static_cast<hipStream_t>(stream);
     // The workspace belongs to (context, stream): calls on one stream serialise by themselves, calls on different streams
     // get different workspaces.  Lookup, growth and the launch happen under one lock, so a concurrent call can never free
@@ -652,7 +656,7 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
 int swmi_semiglobal_release_workspaces(void)
 {
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lock(ctx->ws_mu);
     for (auto &w : ctx->sg_workspaces)
@@ -664,7 +668,7 @@ int swmi_semiglobal_release_workspaces(void)
 int swmi_semiglobal_kernels_for_batch(size_t n, char *sweep, size_t sweep_len, char *traceback, size_t traceback_len)
 {
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     swmi::semiglobal_kernel_names(n, ctx->prop.multiProcessorCount, sweep, sweep_len, traceback, traceback_len);
     return SWMI_OK;
 }
@@ -674,7 +678,7 @@ int swmi_semiglobal_time_device(const void *d_seq1s, const void *d_seq2s, size_t
 {
     if (!phase_ms) return fail(SWMI_ERR_INVALID_ARGUMENT, "phase_ms is NULL");
     if (n == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "n is 0");
-    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
+    if (!current()) return last_status();
     int rc = SWMI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -699,7 +703,7 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     if (!seq1s || !seq2s || !scores || !lengths || (!tracebacks && cap != 0))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
     constexpr size_t kLen = SWMI_SG_LEN;
     // Chunks of up to 8192 alignments (~0.35 MB of workspace + cap*8 B of output each), two sets of device buffers: while
@@ -780,7 +784,7 @@ int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
     if (n_seqs == 0) return SWMI_OK;
     if (!packed || !unpacked) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n_seqs = %zu", n_seqs);
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
     // reuse slot 0: seq1 buffer holds the packed bytes, seq2 buffer the unpacked ones
     const size_t chunk = n_seqs < kChunkPairs ? n_seqs : kChunkPairs;
@@ -806,7 +810,7 @@ int swmi_generate_pairs_device(void *d_seq1s, void *d_seq2s, size_t n, uint64_t 
     if (!d_seq1s || !d_seq2s) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
     if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2s)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned");
-    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
+    if (!current()) return last_status();
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     HIP_TRY(swmi::launch_generate(static_cast<uint8_t *>(d_seq1s), static_cast<uint8_t *>(d_seq2s), n, seed, first_pair, st));
     return SWMI_OK;
@@ -840,7 +844,7 @@ int swmi_time_batch_device(const void *d_seq1s, const void *d_seq2s, size_t n, c
                            int8_t gap_penalty, void *d_scores, void *stream, int iters, float *avg_ms)
 {
     if (!avg_ms || iters <= 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "avg_ms is NULL or iters <= 0");
-    if (!current()) return SWMI_ERR_NOT_INITIALIZED;
+    if (!current()) return last_status();
     int rc = SWMI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);   // NULL = the HIP null (default) stream, as in any HIP call
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -871,7 +875,7 @@ int swmi_queue_create(size_t max_pairs, const int8_t score_matrix[16], int8_t ga
     if (rc != SWMI_OK) return rc;
     if (max_pairs == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "max_pairs is 0");
     Context *ctx = current();
-    if (!ctx) return SWMI_ERR_NOT_INITIALIZED;
+    if (!ctx) return last_status();
     swmi_queue *q = new (std::nothrow) swmi_queue;
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "out of host memory");
     q->ctx = ctx;

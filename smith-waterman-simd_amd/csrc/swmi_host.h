@@ -65,7 +65,8 @@ struct Context {
 
 // ---- state (swmi_api.cpp) ----
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-Context *current();                     // the calling thread's context, made current on its device; nullptr + error text
+int last_status();                      // the code the last fail() on this thread returned
+Context *current();                     // the calling thread's context, made current on its device; nullptr + last_status()
 Context *context_at(int index);         // nullptr if out of range
 int num_contexts();
 std::mutex &init_mutex();
