@@ -208,8 +208,8 @@ SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_
 SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
                                    int32_t *tracebacks, size_t cap, uint32_t *lengths);
 /* Same with every buffer resident in device memory (every pointer 16-byte aligned: the kernels use 16-byte loads and
- * 8-byte stores); asynchronous on `stream`.  The library keeps one workspace per (GPU, stream) of ~0.35 MB per alignment
- * (2-bit predecessor codes, band rows, packed character streams, traceback moves), grown on demand and kept until
+ * 8-byte stores); asynchronous on `stream`.  The library keeps one workspace per (GPU, stream) of ~0.29 MB per alignment
+ * (2-bit predecessor codes, the band's move bits, packed character streams, traceback moves), grown on demand and kept until
  * swmi_semiglobal_release_workspaces() / swmi_shutdown(): calls on one stream serialise by themselves, calls on
  * different streams use different workspaces and may be in flight together, from any threads. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,

@@ -706,7 +706,7 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
     constexpr size_t kLen = SWMI_SG_LEN;
-    // Chunks of up to 8192 alignments (~0.35 MB of workspace + cap*8 B of output each), two sets of device buffers: while
+    // Chunks of up to 8192 alignments (~0.29 MB of workspace + cap*8 B of output each), two sets of device buffers: while
     // the host is busy receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k+1.
     const size_t chunk = n < 8192 ? n : 8192;
     using Set = SgSet;

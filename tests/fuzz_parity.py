@@ -85,15 +85,17 @@ def check(arg):
         oob = ctypes.c_int()
         orc.sg_oracle_xdrop(a.ctypes.data_as(vp), b.ctypes.data_as(vp), ctypes.byref(sc), buf.ctypes.data_as(vp), ctypes.c_size_t(32769), ctypes.byref(ln), ctypes.byref(oob))
     return sc.value == score and ln.value == len(tb) and np.array_equal(buf[: ln.value], tb)
+sg_iter = 0
 while time.time() < t_end:
-    m = 2048
+    m = 2048 - 17 * (sg_iter % 4)        # ragged batches too: the last sweep wavefront is partly filled (interleaved streams, tail lanes)
     a = rng.integers(0, 4, (m, 16384), dtype=np.uint8)
     p = rng.random((m, 1)) * 0.3
     b = np.where(rng.random((m, 16384)) < p, rng.integers(0, 4, (m, 16384), dtype=np.uint8), a).astype(np.uint8)
     for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
         cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
-    os.environ["SWMI_SG_SWEEP"] = str((0, 41, 42, 43, 44, 22, 23, 24)[sg_total // m % 8]); os.environ["SWMI_SG_TRACEBACK"] = str(sg_total // m % 2)
+    os.environ["SWMI_SG_SWEEP"] = str((0, 41, 42, 43, 44, 21, 22, 23, 24)[sg_iter % 9]); os.environ["SWMI_SG_TRACEBACK"] = str(sg_iter // 9 % 2)
+    sg_iter += 1
     scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
     with ThreadPoolExecutor(workers) as ex:
         ok = list(ex.map(check, [(a[k], b[k], int(scores[k]), tbs[k]) for k in range(m)]))
