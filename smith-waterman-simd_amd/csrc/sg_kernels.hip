@@ -34,15 +34,18 @@ constexpr int kDirWords = kMaxRound / 32 + 1;
 constexpr size_t kSplit4MinBatch = 4096;         // band over 4 (later 2) lanes from here on
 constexpr size_t kLaneTracebackMinBatch = 2048;  // one lane per walk (+ expand kernel) from here on
 
-// summary[a].z = band lane of the best cell | kTagFormat when the alignment's code records are in the split sweep's tag
-// format (64 bits per round, band cell k at bits 2k..2k+1: 3 diagonal, 2 up, 1 left) instead of the half-wavefront
-// sweep's two 32-bit words (bit k of word 0 / word 1 = low / high bit of the code 1 diagonal, 2 up, 3 left)
+// Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
+// three-way max: 3 diagonal, 2 up, 1 left (0: round 0 / nothing) -- the reference's tie-break order (source.cpp:1962-1971)
+// falls out of comparing equal values by tag.  The half-wavefront sweep stores them as two 32-bit words per round (bit k
+// of word 0 / word 1 = low / high tag bit of band cell k: the two ballots as they come), the split sweep packed, band
+// cell k at bits 2k..2k+1 of the round's 64 bits; summary[a].z = band lane of the best cell | kTagFormat says which.
+// The traceback's move code: 1 diagonal, 2 up, 3 left = (4 - tag) & 3.
 constexpr int kTagFormat = 1 << 8;
-__device__ __forceinline__ unsigned decode_code(uint2 cw, int bl, bool tag_format)
+__device__ __forceinline__ unsigned decode_code(uint2 cw, int bl, bool packed_tags)
 {
-    const unsigned two_words = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
-    const unsigned tag = ((bl & 16 ? cw.y : cw.x) >> (2 * (bl & 15))) & 3u;
-    return tag_format ? (4u - tag) & 3u : two_words;
+    const unsigned from_words = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
+    const unsigned from_packed = ((bl & 16 ? cw.y : cw.x) >> (2 * (bl & 15))) & 3u;
+    return (4u - (packed_tags ? from_packed : from_words)) & 3u;
 }
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
@@ -67,14 +70,19 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
     return v;
 }
 
-// codes[(a * kMaxRound + r) * 2 + {0,1}]: bit k of word 0 / word 1 = low / high bit of lane k's predecessor code
-// (0 none or dropped, 1 diagonal, 2 up, 3 left); dirs = the band's move bits (above);
+// Sweep for small batches: one band cell per lane, two alignments per wavefront.
+// codes[(a * kCodeStride + r)] = the round's two tag words (above); dirs = the band's move bits (above);
 // summary[a] = {score, best_round, best_lane (| kTagFormat), row of the band's top cell in best_round}
 //
-// A round is one long dependency chain and the kernel is bound by how many instructions it issues per round (8 waves
-// per SIMD keep the issue port busy), so the body is branch-free and every cross-lane step is a DPP move or a v_readlane:
-// an LDS-crossbar shuffle (__shfl*, ds_bpermute_b32) costs more than all of a round's arithmetic.  The predecessor codes
-// fall out of three v_cmp masks combined on the scalar unit (the masks ARE the ballots).
+// A round is one long dependency chain, and with one wavefront per SIMD or fewer (what a small batch gives) EVERY
+// instruction, vector or scalar, costs the wavefront ~5 cycles -- and a v_cndmask_b32 that takes its mask from VCC costs 23
+// (profiles/r02_microbench_valu_rate5.txt).  So the round is written for instruction COUNT: the cell is the tagged
+// v_max3 of the split sweep below (value * 128 + cell * 4 + tag: the winner's tag IS the predecessor code, the band maximum
+// needs no key and no ballot + count-leading-zeros to find the cell), selects are v_bitop3 with all-ones / all-zeros
+// masks, and every cross-lane step is a DPP move or a v_readlane (an LDS-crossbar shuffle costs more than all of a
+// round's arithmetic).  ~95 instructions per round (round 1's formulation: ~128).
+constexpr int kScale = 128;
+
 template <int W>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
@@ -91,10 +99,16 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
     uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kCodeStride;
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
-    const int not_first = keep_opaque(k == 0 ? 0 : -1), not_last = keep_opaque(k == 31 ? 0 : -1);
     const bool writer = real && k == 0;
+    auto pick = [](int m, int if_set, int if_clear) { return (int)__builtin_amdgcn_bitop3_b32((unsigned)m, (unsigned)if_set, (unsigned)if_clear, 0xCA); };
+    constexpr int kDropped = -kScale;                     // value -1: every candidate derived from it is <= 0 and dropped again
+    const int first_mask = keep_opaque(k == 0 ? -1 : 0), last_mask = keep_opaque(k == 31 ? -1 : 0);
+    const int second_mask = keep_opaque(second ? -1 : 0);
+    // per-candidate constants: cell index and tag in the low 7 bits, the -1 of a gap move / mismatch folded in
+    const int c_diag = (k << 2) + 3 - kScale, c_up = (k << 2) + 2 - kScale, c_left = (k << 2) + 1 - kScale;
 
-    int cur = k == 31 ? kXDrop : 0, hor = 0, ver = 0, dia = 0;
+    int cur = k == 31 ? kXDrop * kScale : kDropped;       // clean (value * 128), as are hor / ver
+    int hor = kDropped, ver = kDropped;
     int pos_x = 31;                                       // the reference's now_pos_x (31 leading pads); now_pos_y = round - (pos_x - 31)
     int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0;
     bool alive = true;
@@ -105,61 +119,55 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     for (; round < kMaxRound; ++round) {
         if (!__any(alive)) break;
         // direction of each alignment's band: lane 0 against lane 31 (source.cpp:1895)
-        const bool right_a = __builtin_amdgcn_readlane(cur, 0) < __builtin_amdgcn_readlane(cur, 31);
-        const bool right_b = __builtin_amdgcn_readlane(cur, 32) < __builtin_amdgcn_readlane(cur, 63);
-        const bool right = second ? right_b : right_a;
-        const int from_above = __builtin_amdgcn_update_dpp(0, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) & not_last;   // cur[k+1]
-        const int from_below = __builtin_amdgcn_update_dpp(0, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) & not_first;  // cur[k-1]
-        dia = right ? ver : hor;                          // :1897 / :1908
-        const int nh = right ? cur : from_below;          // :1898 / :1910-1911
-        const int nv = right ? from_above : cur;          // :1899-1900 / :1909
-        hor = nh;
-        ver = nv;
-        pos_x += right ? 1 : 0;
-        // one VALU instruction (per lane, off the round's dependency chain); on the scalar unit it costs six, and this
-        // kernel runs one wavefront per SIMD or less, where every instruction of any kind costs ~5 cycles
-        dir_word = __builtin_amdgcn_alignbit(right ? 0xFFFFFFFFu : 0u, dir_word, 1);
+        const int ra = __builtin_amdgcn_readlane(cur, 0) < __builtin_amdgcn_readlane(cur, 31) ? -1 : 0;      // scalar masks
+        const int rb = __builtin_amdgcn_readlane(cur, 32) < __builtin_amdgcn_readlane(cur, 63) ? -1 : 0;
+        const int rmask = keep_opaque(pick(second_mask, rb, ra));
+        const int above_raw = __builtin_amdgcn_update_dpp(0, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);   // cur[k+1]
+        const int below_raw = __builtin_amdgcn_update_dpp(0, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);   // cur[k-1]
+        const int from_above = pick(last_mask, kDropped, above_raw), from_below = pick(first_mask, kDropped, below_raw);
+        const int dia = pick(rmask, ver, hor);            // :1897 / :1908 (last round's up / left)
+        hor = pick(rmask, cur, from_below);               // left: :1898 / :1910-1911
+        ver = pick(rmask, from_above, cur);               // up:   :1899-1900 / :1909
+        pos_x -= rmask;
+        dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);
         const int pos_y = round - (pos_x - 31);
-        const bool inside = pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;      // :1903, :1913: checked before the round is stored
-        alive = alive && inside;
+        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;         // :1903, :1913: checked before the round is stored
         const int i1 = pos_y + 30 - k;                    // 0-based index into seq1 of this lane's row y = pos_y + 31 - k
         const int i2 = pos_x - 63 + k;                    // 0-based index into seq2 of this lane's column x = pos_x - 62 + k
-        const int l1 = seq1s[seq_base + (uint32_t)min(max(i1, 0), kLen - 1)];
-        const int l2 = seq2s[seq_base + (uint32_t)min(max(i2, 0), kLen - 1)];
-        const int c1 = (unsigned)i1 < (unsigned)kLen ? l1 : 0xF0;             // pads, source.cpp:1861-1873
-        const int c2 = (unsigned)i2 < (unsigned)kLen ? l2 : 0xF1;
-        const int s = (c1 == c2 && c1 < 4) ? 1 : -1;      // :1918-1920 (a pad never equals anything)
-        const int vd = dia != 0 ? dia + s : 0;            // :1922
-        const int vu = sat_dec(ver);                      // :1924, 0 stays 0
-        const int vl = sat_dec(hor);                      // :1923
+        const unsigned l1 = seq1s[seq_base + (uint32_t)min(max(i1, 0), kLen - 1)];
+        const unsigned l2 = seq2s[seq_base + (uint32_t)min(max(i2, 0), kLen - 1)];
+        // a match needs both positions inside their sequences (pads never match, source.cpp:1861-1873) and a base < 4
+        // (:1918-1920): "i outside [0, kLen)" = sign bit of i | (kLen - 1 - i)
+        const unsigned outside = (unsigned)(i1 | (kLen - 1 - i1) | i2 | (kLen - 1 - i2)) >> 31;                // 0 / 1
+        const unsigned differ = (l1 ^ l2) | (l1 >> 2) | outside;                                                // 0 (a match) .. 255
+        const int f = (int)((differ - 1u) & (2u * kScale));   // 256 for a match, 0 otherwise: bit 8 of differ - 1 (no compare, no select)
+        const int vd = dia + f + c_diag;                  // dia + 1 / dia - 1, tag 3   (:1922)
+        const int vu = ver + c_up;                        // up - 1, tag 2              (:1924)
+        const int vl = hor + c_left;                      // left - 1, tag 1            (:1923)
         const int m1 = vd > vu ? vd : vu;
-        const int v0 = m1 > vl ? m1 : vl;                 // >= 0
+        const int v0 = m1 > vl ? m1 : vl;                 // v_max3_i32: value, cell, winning tag
         const int rm = row16_max(v0);
-        const int best_a = max(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
-        const int best_b = max(__builtin_amdgcn_readlane(rm, 32), __builtin_amdgcn_readlane(rm, 48));
-        const int round_best = second ? best_b : best_a;
-        const int gain = alive ? round_best : 0;
-        const bool improved = gain > best;                // :1933-1936
-        const unsigned long long hit = __ballot(v0 == round_best);
-        const unsigned mine = second ? (unsigned)(hit >> 32) : (unsigned)hit;
-        best = improved ? gain : best;
-        best_round = improved ? round : best_round;
-        best_lane = improved ? 31 - __builtin_clz(mine) : best_lane;          // the search of :1957-1958 walks down from lane 31
-        best_top = improved ? pos_y : best_top;
-        const int v = v0 < best - kXDrop ? 0 : v0;        // :1938-1941
-        // predecessor code in the reference's tie-break order (diag, up, left; :1962-1971): 1 / 2 / 3, 0 for a dropped cell.
-        // v != 0 && vd == v implies dia != 0 (and likewise for up), so three compare masks are enough.
-        const unsigned long long m_nz = __ballot(v != 0), m_d = __ballot(vd == v), m_u = __ballot(vu == v);
-        const unsigned long long bit0 = m_nz & (m_d | ~m_u), bit1 = m_nz & ~m_d;
-        if (alive && writer) {
-            my_codes[round] = second ? make_uint2((unsigned)(bit0 >> 32), (unsigned)(bit1 >> 32))
-                                     : make_uint2((unsigned)bit0, (unsigned)bit1);
-        }
+        const int kmax_a = max(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
+        const int kmax_b = max(__builtin_amdgcn_readlane(rm, 32), __builtin_amdgcn_readlane(rm, 48));
+        const int kmax = pick(second_mask, kmax_b, kmax_a);                    // value, then the highest cell among equals (:1957-1958)
+        const int band_best = kmax >> 7;
+        const int round_best = band_best > 0 ? band_best : 0;
+        const bool improved = alive && round_best > best; // :1933-1936
+        const int imask = keep_opaque(improved ? -1 : 0);
+        best = pick(imask, round_best, best);
+        best_round = pick(imask, round, best_round);
+        best_lane = pick(imask, (kmax >> 2) & 31, best_lane);
+        best_top = pick(imask, pos_y, best_top);
+        const int thr = (best - kXDrop > 1 ? best - kXDrop : 1) * kScale;      // :1938-1941, and "0 means dropped"
+        const int below_thr = keep_opaque(v0 - thr) >> 31;
+        cur = (int)__builtin_amdgcn_bitop3_b32((unsigned)v0, (unsigned)below_thr, (unsigned)~(kScale - 1), 0xA8);   // (v0 | dropped) & clean
+        // the winners' tags, as two ballots: word 0 = low tag bits, word 1 = high tag bits of the 32 band cells
+        const unsigned long long t0 = __ballot((v0 & 1) != 0), t1 = __ballot((v0 & 2) != 0);
+        if (writer) my_codes[round] = second ? make_uint2((unsigned)(t0 >> 32), (unsigned)(t1 >> 32)) : make_uint2((unsigned)t0, (unsigned)t1);
         if ((round & 31) == 31) {                         // (a running pointer: `(round >> 5) * n` would be recomputed every round)
             if (writer) *my_dirs = dir_word;
             my_dirs += n;
         }
-        cur = alive ? v : cur;
         alive = alive && round_best != 0;                 // :1943-1946
     }
     const int last_round = round - 1;                     // the last round that ran
@@ -168,7 +176,6 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
     }
 }
-
 
 // ---- character streams for the split sweep -------------------------------------------------------------------------
 //
@@ -246,7 +253,6 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
 //     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells.
 // Stored value of a cell between rounds: value * 128 + (first cell of the lane) * 4  ("clean"; the lane's share of the
 // index stays in, the cell's own share and the tag are added with the candidate constants).
-constexpr int kScale = 128;
 
 template <int G, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
@@ -514,7 +520,7 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride;
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]
     int4 sum = summary[a];
-    const bool tag_format = (sum.z & kTagFormat) != 0;
+    const bool tag_format = (sum.z & kTagFormat) != 0;      // packed tags (split sweep) / two tag words (half-wavefront sweep)
     sum.z &= 31;
     const int y0 = sum.w + 31 - sum.z;                    // .w = row of the band's top cell in the best round
     const int x0 = sum.y - y0;
@@ -622,7 +628,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
     unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     int4 sum = summary[a];
-    const bool tag_format = (sum.z & kTagFormat) != 0;
+    const bool tag_format = (sum.z & kTagFormat) != 0;      // packed tags (split sweep) / two tag words (half-wavefront sweep)
     sum.z &= 31;
     int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
     int x = sum.y - y;                                    // y + x = the round of the best cell
