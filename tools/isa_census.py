@@ -39,7 +39,7 @@ FULL = {  # 2-cycle class
     "v_lshrrev_b32": 2.25, "v_ashrrev_i32": 2.27, "v_mov_b32": 2.21, "v_max_i16": 2.25, "v_max_u16": 2.30,
     "v_min_i16": 2.25, "v_min_u16": 2.30, "v_add_u16": 2.30, "v_sub_u16": 2.26, "v_subrev_u16": 2.26, "v_fma_f32": 2.29,
     "v_fmac_f32": 2.28, "v_add_f32": 2.33, "v_sub_f32": 2.33, "v_mul_f32": 2.26, "v_max_f16": 2.30, "v_add_f16": 2.24,
-    "v_bitop3_b32": 2.30, "v_accvgpr_write_b32": 2.21, "v_accvgpr_read_b32": 2.21, "v_accvgpr_mov_b32": 2.21,
+    "v_bitop3_b32": 2.37, "v_not_b32": 2.25, "v_accvgpr_write_b32": 2.21, "v_accvgpr_read_b32": 2.21, "v_accvgpr_mov_b32": 2.21,
 }
 HALF = {  # 4-cycle class
     "v_max_i32": 4.09, "v_max_u32": 4.15, "v_max3_u32": 4.15, "v_min3_u32": 4.15, "v_min_i32": 4.13, "v_min_u32": 4.15, "v_max3_i32": 4.13, "v_min3_i32": 4.17,
@@ -51,13 +51,16 @@ HALF = {  # 4-cycle class
     "v_add_i32": 4.19, "v_max_f32": 4.15, "v_min_f32": 4.15, "v_max3_f32": 4.17, "v_sad_u8": 4.17,
     "v_pk_add_u16": 4.16, "v_pk_max_i16": 4.16, "v_pk_max_u16": 4.16, "v_pk_sub_u16": 4.16, "v_pk_mad_i16": 4.16,
     "v_pk_add_f16": 4.08, "v_mad_legacy_u16": 4.17,
+    # profiles/r02_microbench_valu_rate5.txt (8 wavefronts per SIMD)
+    "v_lshlrev_b64": 4.27, "v_lshrrev_b64": 4.28, "v_ashrrev_i64": 4.28, "v_lshl_add_u64": 4.22, "v_mov_b64": 4.26,
+    "v_readfirstlane_b32": 4.25, "v_readlane_b32": 4.32, "v_bcnt_u32_b32": 4.28, "v_ffbh_u32": 4.21, "v_ffbl_b32": 4.21,
+    "v_bfm_b32": 4.21, "v_dot2_i32_i16": 4.27, "v_dot8_i32_i4": 4.18, "v_pk_maximum3_f16": 4.23, "v_pk_max_f16": 4.28,
 }
 QUARTER = {  # 8-cycle class
     "v_max3_i16": 8.43, "v_max3_u16": 8.44, "v_med3_i16": 8.46, "v_mad_i16": 8.18, "v_add_i16": 8.15, "v_sub_i16": 8.15,
 }
-# v_cmp_* / v_readlane / v_readfirstlane / 64-bit shifts and adds were not measured: priced at 4 and reported as
-# `unmeasured` so that a reader can see how much of the total rests on the default (none of it inside the main loops of
-# the kernels this repository ships, apart from the v_cmp of the semi-global sweep).
+# Anything else is priced at 4 and reported as `unmeasured`, so that a reader can see how much of a total rests on the
+# default.  v_cmp_* (every compare, VCC or SGPR-pair destination) measured 4.05 - 4.35 and is matched by prefix below.
 DEFAULT_COST = 4.0
 
 
@@ -138,6 +141,8 @@ def cost_of(op):
         return "valu_half", 4.0, HALF[base]
     if base in QUARTER:
         return "valu_quarter", 8.0, QUARTER[base]
+    if base.startswith("v_cmp_") or base.startswith("v_cmpx_"):
+        return "valu_half", 4.0, 4.3
     return "valu_unmeasured", DEFAULT_COST, DEFAULT_COST
 
 
