@@ -481,16 +481,27 @@ def row_summary(line):
     return out
 
 
-def sw128_roofline(swmi, P, lanes, flags, mode, kernel_ms, match, mismatch, gap):
-    """`roofline` object of one sw128_kernel launch over P pairs."""
-    sm_gap_fits = all(-128 <= v + gap <= 127 for v in (match, mismatch))
-    fold = 1 if (sm_gap_fits and not (flags & 1)) else 0
+def sw128_roofline(swmi, P, sched_lanes, sched_flags, mode, kernel_ms, match, mismatch, gap):
+    """`roofline` object of one scoring launch over P pairs under the schedule setting (sched_lanes, sched_flags) -- 0 lanes
+    = automatic.  The library says which kernel instantiation such a launch runs (swmi_score_kernel_for_batch)."""
+    import re
     mode_id = {"pairs": 0, "packed": 1, "one-vs-many": 2}[mode]
-    trips = (128 + lanes) // 2                   # T2 of sw128_kernel: pairs of anti-diagonal steps
-    waves = (P + 64 // lanes - 1) // (64 // lanes)
+    cur = swmi.get_schedule()
+    swmi.set_schedule(sched_lanes, sched_flags)
+    try:
+        kernel, per_wave = swmi.score_kernel_for_batch(P, swmi.match_matrix(match, mismatch), gap, mode_id)
+    finally:
+        swmi.set_schedule(*cur)
+    packed_kernel = kernel.startswith("sw128_pk_kernel")
+    lanes = 4 if packed_kernel else int(re.search(r"<(\d+)", kernel).group(1))
+    trips = (128 + lanes) // 2                   # T2 of the scorers: pairs of anti-diagonal steps
+    waves = (P + per_wave - 1) // per_wave
     kernel_s = kernel_ms * 1e-3
-    roof = issue_bound(r"^sw128_kernel<%d,%d,%d,%d>$" % (lanes, fold, 1 if flags & 2 else 0, mode_id), trips, waves, kernel_ms,
-                       marker=("v_dot4_i32_i8", 2 * (128 // lanes)))     # one v_dot4 per cell, 2 steps x R cells per source iteration
+    # what marks one source iteration in the compiled loop: one v_perm per PAIR of cells (packed kernel: 2 steps x 32 rows),
+    # one v_dot4 per cell (int32 kernel: 2 steps x R rows)
+    marker = ("v_perm_b32", 64) if packed_kernel else ("v_dot4_i32_i8", 2 * (128 // lanes))
+    roof = issue_bound("^" + re.escape(kernel) + "$", trips, waves, kernel_ms, marker=marker)
+    roof["lanes_per_alignment"] = lanes
     bytes_per_alignment = {"pairs": BYTES_PER_ALIGNMENT, "packed": 32 + 32 + 4, "one-vs-many": 128 + 4}[mode]
     roof.update({
         "kernel_ms": round(kernel_ms, 4), "traffic": None,
@@ -559,7 +570,7 @@ def single_gpu(args, swmi, np, torch, local_rank):
     timed = [ev for ev in events if ev is not None]
     kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)      # HIP events on the launch stream
     value = P * args.steps / elapsed
-    roof = sw128_roofline(swmi, P, lanes, flags, args.mode, kernel_ms, args.match, args.mismatch, args.gap)
+    roof = sw128_roofline(swmi, P, args.lanes, flags, args.mode, kernel_ms, args.match, args.mismatch, args.gap)
     prof, prof_src = stamped_profile(roof.get("kernel_code_sha256"))
     if prof and prof.get("pairs_per_launch") == P and args.mode == "pairs":
         roof["traffic"] = prof.get("hbm_bytes_per_launch")
@@ -638,7 +649,7 @@ def single_gpu(args, swmi, np, torch, local_rank):
         finally:
             swmi.set_schedule(args.lanes, 0)
         got = out2.cpu().numpy()
-        r = sw128_roofline(swmi, P, lanes_row or swmi.schedule_for_batch(P), 0, mode, ms, args.match, args.mismatch, args.gap)
+        r = sw128_roofline(swmi, P, lanes_row, 0, mode, ms, args.match, args.mismatch, args.gap)
         row = {"value": round(P / (ms * 1e-3), 1), "unit": "alignments/s", "kernel": r.get("kernel"), "kernel_ms": r["kernel_ms"],
                "frac": r.get("frac"), "frac_at_measured_instruction_rates": r.get("frac_at_measured_instruction_rates"),
                "gcups_kernel": r["gcups_kernel"], "steps": 20, "workload": workload}
@@ -665,28 +676,32 @@ def single_gpu(args, swmi, np, torch, local_rank):
     ms111 = time_launches(torch, stream, lambda: swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm111, 1, scores.data_ptr(),
                                                                          stream.cuda_stream), 20, 5)
     want111, who = oracle_scores(np, a_h, b_h, sm111, 1)
-    r111 = sw128_roofline(swmi, P, lanes, flags, "pairs", ms111, 1, -1, 1)
+    r111 = sw128_roofline(swmi, P, args.lanes, 0, "pairs", ms111, 1, -1, 1)
     rows["fixed_111_scorer"] = {"value": round(P / (ms111 * 1e-3), 1), "unit": "alignments/s", "kernel": r111.get("kernel"),
                                 "kernel_ms": r111["kernel_ms"], "frac": r111.get("frac"), "steps": 20,
                                 "gpu_mismatches": int((want111 != scores[:4096].cpu().numpy()).sum()), "checked_against": "%s, first 4096 pairs" % who,
-                                "workload": "SURVEY 8f N2: sm +1/-1, gap 1 (SmithWaterman_8bit111simd, source.cpp:1105-1225) on the general kernel"}
-    # ... and the one alternative cell that ties on paper for these parameters -- 16-bit state, three full-rate v_max_i16
-    # instead of v_max3_i32 + the running max (schedule flags 1 | 2: h = max(max(left, up) -sat gap, dot4)) -- measured
-    # beside it: the negative result of DESIGN.md section 5.1
-    swmi.set_schedule(args.lanes, 3)
-    try:
-        ms111_16 = time_launches(torch, stream, lambda: swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, sm111, 1, scores.data_ptr(),
-                                                                               stream.cuda_stream), 20, 5)
-    finally:
-        swmi.set_schedule(args.lanes, 0)
-    r111_16 = sw128_roofline(swmi, P, lanes, 3, "pairs", ms111_16, 1, -1, 1)
-    rows["fixed_111_scorer_16bit_cell"] = {"value": round(P / (ms111_16 * 1e-3), 1), "unit": "alignments/s", "kernel": r111_16.get("kernel"),
-                                           "kernel_ms": r111_16["kernel_ms"], "frac": r111_16.get("frac"), "steps": 20,
-                                           "gpu_mismatches": int((want111 != scores[:4096].cpu().numpy()).sum()),
-                                           "checked_against": "%s, first 4096 pairs" % who,
-                                           "speedup_over_general_kernel": round(ms111 / ms111_16, 3),
-                                           "workload": "the same with the 16-bit cell body (swmi_set_schedule flags 1|2): the specialisation "
-                                                       "experiment for row N2; not faster, so the general kernel stays"}
+                                "workload": "SURVEY 8f N2: sm +1/-1, gap 1 (SmithWaterman_8bit111simd, source.cpp:1105-1225): every folded score "
+                                            ">= 0, so the packed kernel runs without its bias subtraction (9 issue cycles per cell)"}
+    # the int32 kernel (round 1's cell: v_dot4 + v_max3_i32 + v_sub, schedule flag 8) on the same two parameter sets: what the
+    # packed kernel is measured against
+    def int32_row(name, match, mismatch, gap, ms_packed, workload):
+        smx = swmi.match_matrix(match, mismatch)
+        swmi.set_schedule(args.lanes, 8)
+        try:
+            ms = time_launches(torch, stream, lambda: swmi.score_batch_device(d1.data_ptr(), d2.data_ptr(), P, smx, gap, scores.data_ptr(),
+                                                                             stream.cuda_stream), 20, 5)
+        finally:
+            swmi.set_schedule(args.lanes, 0)
+        got = scores[:4096].cpu().numpy()
+        want_x, who_x = oracle_scores(np, a_h, b_h, smx, gap)
+        r = sw128_roofline(swmi, P, args.lanes, 8, "pairs", ms, match, mismatch, gap)
+        rows[name] = {"value": round(P / (ms * 1e-3), 1), "unit": "alignments/s", "kernel": r.get("kernel"), "kernel_ms": r["kernel_ms"],
+                      "frac": r.get("frac"), "steps": 20, "gpu_mismatches": int((want_x != got).sum()),
+                      "checked_against": "%s, first 4096 pairs" % who_x, "packed_kernel_speedup_over_this": round(ms / ms_packed, 3),
+                      "workload": workload}
+    int32_row("int32_cell_kernel", args.match, args.mismatch, args.gap, kernel_ms,
+              "the headline batch on the int32 kernel (swmi_set_schedule flag 8: one alignment per 4 lanes, v_dot4 lookup)")
+    int32_row("fixed_111_scorer_int32_cell_kernel", 1, -1, 1, ms111, "sm +1/-1, gap 1 on the int32 kernel")
     del d1, d2, scores
     torch.cuda.empty_cache()
     rows["banded_affine_1024"] = row_summary(bench_banded(args, swmi, np, torch, local_rank, steps=10, warmup=3))
@@ -798,7 +813,7 @@ def multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank):
                 checked += m
         lanes, flags = swmi.get_schedule()
         lanes = lanes or swmi.schedule_for_batch(P)
-        roof = sw128_roofline(swmi, P, lanes, flags, "pairs", kernel_ms, args.match, args.mismatch, args.gap)
+        roof = sw128_roofline(swmi, P, args.lanes, flags, "pairs", kernel_ms, args.match, args.mismatch, args.gap)
         roof["kernel_ms_note"] = "rank 0's kernel; every rank's is in legs.*.kernel_ms_per_rank"
         line = {
             "metric": "alignments/sec (and GCUPS) on 1M fixed-length pairs, 1/2/4/8 MI355X",

@@ -250,11 +250,21 @@ SWMI_API int swmi_queue_destroy(swmi_queue *q);
  * launch on (fewest instructions per cell), more lanes per alignment below that (lowest latency: L = 64 up to 2048 pairs);
  * swmi_get_schedule reports 0 in that case.
  * flags (all give identical scores): bit 0 = never fold the gap into the matrix rows (general cell body);
- * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only). */
+ * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only);
+ * bit 3 = never the packed kernel.  (Without it, L = 4 -- also what the automatic choice resolves to for large batches --
+ * runs sw128_pk_kernel: two alignments per register, 16-bit cells, v_pk_maximum3_f16 as a packed integer max; ~1.15x
+ * the int32 kernel in general and ~1.4x when every score_matrix entry + gap_penalty is >= 0, e.g. the (1,-1,1) parameters
+ * of the reference's SmithWaterman_8bit111simd, source.cpp:1105-1225.  DESIGN.md section 5.) */
 SWMI_API int swmi_set_schedule(int lanes_per_alignment, unsigned flags);
 SWMI_API int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags);
 /* Lanes per alignment a launch of n pairs runs with under the current setting (what 0 = automatic resolves to). */
 SWMI_API int swmi_schedule_for_batch(size_t n);
+/* Which kernel instantiation a launch of n pairs with these parameters runs under the current setting, e.g.
+ * "sw128_pk_kernel<0,1>" or "sw128_kernel<64,1,0,0>" (template arguments as tools/isa_census.py prints them), and how many
+ * alignments one of its wavefronts scores.  mode: 0 = pairs, 1 = 2-bit packed input, 2 = one-vs-many.  For profiling
+ * tools and bench.py, which derive the issue-bound fraction from the disassembly of exactly that kernel. */
+SWMI_API int swmi_score_kernel_for_batch(size_t n, const int8_t score_matrix[16], int8_t gap_penalty, int mode,
+                                         char *name, size_t name_len, int *alignments_per_wavefront);
 
 /* ---- synthetic inputs ----------------------------------------------------
  * Counter-based generator, identical on host and device: pair p, sequence s (0/1), 64-bit

@@ -325,6 +325,162 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 }
 
 
+// ---- packed kernel: two alignments per register, any parameters (L = 4) -----------------------------------------------
+//
+// gfx950's new v_pk_maximum3_f16 is, for NON-NEGATIVE 16-bit integers below 0x7C00, a packed THREE-INPUT INTEGER MAX:
+// such integers order exactly like the IEEE half-precision numbers with the same bit patterns (denormals included; hipcc
+// kernels keep f16 denormals; tools/experiments/pk_max3_probe.hip checks the claim on 1M random triples).  Two cells' max3
+// in one half-rate instruction (v_max3_i32 does one) is what makes 16-bit packing pay on this VALU -- with v_pk_max_i16
+// alone it only ties with the int32 cell.  Every value of the gap-folded recurrence can be kept
+// non-negative and below 16 512:
+//     sc = s + gap + Q >= 0            (Q = max(0, -(min s + gap)); one byte: s + gap + Q <= 255 for every int8 matrix)
+//     t  = (H(i-1,j-1) + sc) -sat Q    (the folded diagonal term, floored at 0: a negative t never wins the max below)
+//     x  = max3(left, up, t),   H = x -sat gap
+// When every s + gap is already >= 0 -- (1,-1,1), the parameters of SmithWaterman_8bit111simd / _8b111x32
+// (source.cpp:1105-1522), are the model case -- Q = 0 and the second subtraction disappears (BIAS = false).
+//   * one VGPR holds the SAME row of TWO alignments (low / high half), so there is no dependency inside a pair and the
+//     two alignments share every instruction; a lane group of L = 4 lanes walks two alignments, a wavefront 32;
+//   * score lookup for both halves = ONE v_perm_b32: its 8 source bytes are the 4 scores of the row for alignment X and
+//     for alignment Y, its selector -- staged per column in LDS in place of the one-hot -- picks score[X][base of X's
+//     column] into byte 0 and score[Y][base of Y's column] into byte 2 (zero bytes between; pad columns select zeros);
+//   * t = v_pk_add_u16 (+ v_pk_sub_u16 clamp), x = v_pk_maximum3_f16, H = v_pk_sub_u16 clamp, running best =
+//     v_pk_maximum3_f16 over two cells: 18 (Q = 0) / 22 issue cycles per 2 cells = 9 / 11 per cell, every instruction in
+//     the half-rate class -- which, unlike the int32 cell's full-rate third, issues at its nominal rate at 4 wavefronts per
+//     SIMD.
+// Same anti-diagonal pipeline, DPP hand-over and pad-column argument as sw128_kernel (header of this file).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));    // (not volatile: a pure function, freely scheduled)
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);                        // v_pk_add_u16
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
+{
+    const u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));   // v_pk_sub_u16 ... clamp
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+template <int MODE, bool BIAS>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
+                uint32_t n, SmRows rows /* s + gap + Q, every byte in [0, 255] */, int gap, int q)
+{
+    constexpr int L = 4, R = kSeqLen / L;   // lanes per pair of alignments, rows per lane
+    constexpr int G = 64 / L;               // lane groups per wavefront, each walking TWO alignments
+    constexpr int A = 2 * G;                // alignments per wavefront
+    constexpr int PAD = L + 2;
+    constexpr int S = kSeqLen + 2 * PAD;
+    constexpr int T2 = (kSeqLen + L) / 2;
+    constexpr int NW = R / 4;
+    constexpr uint32_t kZeroSel = 0x0C0C0C0Cu;              // v_perm selector 0x0C = constant 0x00
+
+    __shared__ uint32_t lds_sel[kWavesPerBlock][G * S];     // per column of an alignment pair: the v_perm selector
+    __shared__ uint32_t lds_rows[kWavesPerBlock][4];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = lane / L, j = lane % L;
+    const uint32_t first = (blockIdx.x * kWavesPerBlock + wv) * A;
+    if (first >= n) return;                 // wave-uniform
+    uint32_t px = first + 2 * g, py = px + 1;                // the lane group's two alignments
+    const bool live_x = px < n, live_y = py < n;
+    if (!live_x) px = n - 1;                // ragged tail: recompute the last pair, do not store
+    if (!live_y) py = n - 1;
+
+    uint32_t ax[NW], bx[NW], ay[NW], by[NW];
+    if constexpr (MODE == 1) {
+        load_bases_packed<R>(seq1s + (size_t)px * 32 + j * (R / 4), ax);
+        load_bases_packed<R>(seq2s + (size_t)px * 32 + j * (R / 4), bx);
+        load_bases_packed<R>(seq1s + (size_t)py * 32 + j * (R / 4), ay);
+        load_bases_packed<R>(seq2s + (size_t)py * 32 + j * (R / 4), by);
+    } else {
+        load_bases<R>(seq1s + (size_t)px * kSeqLen + j * R, ax);
+        load_bases<R>(seq2s + (MODE == 2 ? (size_t)0 : (size_t)px * kSeqLen) + j * R, bx);
+        load_bases<R>(seq1s + (size_t)py * kSeqLen + j * R, ay);
+        load_bases<R>(seq2s + (MODE == 2 ? (size_t)0 : (size_t)py * kSeqLen) + j * R, by);
+    }
+
+    if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
+    uint32_t *prof = &lds_sel[wv][g * S];
+    for (int k = j; k < PAD; k += L) {
+        prof[k] = kZeroSel;
+        prof[PAD + kSeqLen + k] = kZeroSel;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint32_t cx = (bx[i / 4] >> (8 * (i % 4))) & 3u, cy = (by[i / 4] >> (8 * (i % 4))) & 3u;
+        // byte 0 <- source byte cx (X's row scores), byte 2 <- source byte 4 + cy (Y's row scores), bytes 1 and 3 <- 0x00
+        prof[PAD + j * R + i] = cx | 0x0C00u | ((4u + cy) << 16) | 0x0C000000u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    uint32_t tx[R], ty[R];                  // folded scores (4 bytes, one per column base) of row i for X / for Y
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        tx[i] = lds_rows[wv][(ax[i / 4] >> (8 * (i % 4))) & 3u];
+        ty[i] = lds_rows[wv][(ay[i / 4] >> (8 * (i % 4))) & 3u];
+    }
+    __builtin_amdgcn_s_setprio(2);
+
+    uint32_t h[R];                          // H(row i, previous column): X in the low half, Y in the high half
+#pragma unroll
+    for (int i = 0; i < R; ++i) h[i] = 0;
+    uint32_t best = 0, u0 = 0, u1 = 0;
+    const uint32_t gap2 = (uint32_t)gap | ((uint32_t)gap << 16);
+    const uint32_t q2 = (uint32_t)q | ((uint32_t)q << 16);
+    const int group_mask = keep(j == 0 ? 0 : -1);
+    const uint32_t *col = prof + PAD - j;   // col[t] = selector of column t - j
+
+    auto step = [&](uint32_t sel, uint32_t up, uint32_t diag) {
+        uint32_t dprev = diag, xprev = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const uint32_t left = h[i];
+            const uint32_t sc = __builtin_amdgcn_perm(ty[i], tx[i], sel);        // {S0 = Y's scores: bytes 4..7, S1 = X's: bytes 0..3}
+            uint32_t t = pk_add(dprev, sc);
+            if constexpr (BIAS) t = pk_sub_sat(t, q2);
+            const uint32_t x = pk_max3(left, up, t);
+            if (i & 1) best = pk_max3(best, xprev, x);
+            xprev = x;
+            const uint32_t hn = pk_sub_sat(x, gap2);
+            h[i] = hn;
+            up = hn;
+            dprev = left;
+        }
+        return (uint32_t)from_prev_lane<L>((int)h[R - 1], group_mask);
+    };
+
+    uint32_t e0 = col[0];
+    for (int t2 = 0; t2 < T2; ++t2) {
+        const uint32_t e1 = col[2 * t2 + 1];
+        const uint32_t e2 = col[2 * t2 + 2];
+        u1 = step(e0, u0, u1);
+        u0 = step(e1, u1, u0);
+        e0 = e2;
+    }
+
+    // reduce over the L lanes of the group (packed), then unfold the gap: the maximum was tracked on x = H + gap
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+        best = pk_max3(best, other, other);
+    }
+    const int bx_score = (int)(best & 0xFFFFu), by_score = (int)(best >> 16);
+    if (j == 0) {
+        if (live_x) scores[px] = bx_score > gap ? bx_score - gap : 0;
+        if (live_y) scores[py] = by_score > gap ? by_score - gap : 0;
+    }
+}
+
 // ---- LDS score fetch for the lookup variant ---------------------------------------------------------
 // ds_read_i8 returns the sign-extended byte, so the consumer is a plain full-rate v_add_u32.  (Left to itself hipcc
 // turns half of these into ds_read_u8 + v_add_u32_sdwa, a half-rate add.)  The loads are inline asm, so the compiler
@@ -721,6 +877,15 @@ hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s
     if (blocks > 0x7fffffffull || n > 0xffffffffull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
     const uint32_t n32 = (uint32_t)n;
+    if constexpr (L == 4) {
+        if (cfg.use_pk) {                   // two alignments per register (rows = s + gap + pk_bias, one byte each)
+            const size_t waves_pk = (n + 31) / 32;
+            const dim3 grid_pk((unsigned)((waves_pk + kWavesPerBlock - 1) / kWavesPerBlock));
+            if (cfg.pk_bias) hipLaunchKernelGGL((sw128_pk_kernel<MODE, true>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, cfg.pk_bias);
+            else             hipLaunchKernelGGL((sw128_pk_kernel<MODE, false>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0);
+            return hipGetLastError();
+        }
+    }
     if constexpr (L <= 16 && L >= 4) {
         if (cfg.fold_gap && cfg.use_lut) {
             hipLaunchKernelGGL((sw128_lut_kernel<L, MODE>), grid, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap);

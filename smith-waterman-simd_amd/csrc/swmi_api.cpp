@@ -112,6 +112,21 @@ LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *
         if (v < -128 || v > 127) fold = false;
     }
     cfg.fold_gap = fold;
+    // L = 4 with no A/B variant asked for runs the packed kernel (two alignments per register): its rows hold
+    // s + gap + Q as unsigned bytes, Q = max(0, -(min s + gap)), which fits one byte for every int8 matrix and gap <= 127
+    cfg.use_pk = cfg.lanes_per_alignment == 4 && !(flags & (swmi::kNoPacked | swmi::kNoGapFold | swmi::kUseI16 | swmi::kUseLut));
+    cfg.pk_bias = 0;
+    if (cfg.use_pk) {
+        int lowest = 255;
+        for (int k = 0; k < 16; ++k) lowest = int(sm[k]) + gap < lowest ? int(sm[k]) + gap : lowest;
+        cfg.pk_bias = lowest < 0 ? -lowest : 0;
+        for (int a = 0; a < 4; ++a) {
+            uint32_t r = 0;
+            for (int b = 0; b < 4; ++b) r |= uint32_t(int(sm[4 * a + b]) + gap + cfg.pk_bias) << (8 * b);
+            rows->r[a] = r;
+        }
+        return cfg;
+    }
     *rows = pack_rows(sm, fold ? gap : 0);
     return cfg;
 }
@@ -401,7 +416,7 @@ int swmi_set_schedule(int lanes_per_alignment, unsigned flags)
 {
     if (lanes_per_alignment != 0 && !swmi::schedule_supported(lanes_per_alignment))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "lanes_per_alignment must be one of 64,32,16,8,4,2 (got %d)", lanes_per_alignment);
-    if (flags & ~7u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
+    if (flags & ~15u) return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown schedule flags 0x%x", flags);
     g_schedule.store(uint64_t(uint32_t(lanes_per_alignment)) | (uint64_t(flags) << 32));
     return SWMI_OK;
 }
@@ -415,6 +430,29 @@ int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags)
 }
 
 int swmi_schedule_for_batch(size_t n) { return resolve_lanes(g_schedule.load(), n); }
+
+int swmi_score_kernel_for_batch(size_t n, const int8_t score_matrix[16], int8_t gap_penalty, int mode, char *name,
+                                size_t name_len, int *alignments_per_wavefront)
+{
+    int rc = check_params(score_matrix, gap_penalty);
+    if (rc != SWMI_OK) return rc;
+    if (mode < 0 || mode > 2 || !name || name_len == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "mode %d outside 0..2, or no name buffer", mode);
+    Context dummy;                          // make_config reads only extra_lds from the context
+    SmRows rows;
+    const LaunchConfig cfg = make_config(dummy, score_matrix, gap_penalty, &rows, n);
+    const int L = cfg.lanes_per_alignment;
+    int per_wave = 64 / L;
+    if (cfg.use_pk) {
+        snprintf(name, name_len, "sw128_pk_kernel<%d,%d>", mode, cfg.pk_bias ? 1 : 0);
+        per_wave = 32;
+    } else if (cfg.fold_gap && cfg.use_lut && L >= 4 && L <= 16) {
+        snprintf(name, name_len, "sw128_lut_kernel<%d,%d>", L, mode);
+    } else {
+        snprintf(name, name_len, "sw128_kernel<%d,%d,%d,%d>", L, cfg.fold_gap ? 1 : 0, cfg.use_i16 ? 1 : 0, mode);
+    }
+    if (alignments_per_wavefront) *alignments_per_wavefront = per_wave;
+    return SWMI_OK;
+}
 
 int swmi_get_device_info(swmi_device_info *info)
 {

@@ -30,6 +30,7 @@ ERR_QUEUE_FULL = -8
 NO_GAP_FOLD = 1
 USE_I16 = 2
 USE_LUT = 4
+NO_PACKED = 8
 
 
 class SwmiError(RuntimeError):
@@ -76,6 +77,7 @@ def load():
     lib.swmi_sharded_gathered_host.argtypes = [vp, ctypes.c_int, vp]
     lib.swmi_sharded_time.argtypes = [vp, vp, i8, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+    lib.swmi_score_kernel_for_batch.argtypes = [sz, vp, i8, ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int)]
     lib.swmi_semiglobal_kernels_for_batch.argtypes = [sz, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
     lib.swmi_score_pair.argtypes = [vp, vp, vp, i8]
     lib.swmi_score_batch.argtypes = [vp, vp, sz, vp, i8, vp]
@@ -197,6 +199,14 @@ def get_schedule():
 def schedule_for_batch(n):
     """Lanes per alignment a launch of n pairs runs with (what the automatic setting resolves to)."""
     return int(load().swmi_schedule_for_batch(ctypes.c_size_t(n)))
+
+
+def score_kernel_for_batch(n, score_matrix, gap_penalty, mode=0):
+    """(kernel instantiation name, alignments per wavefront) a launch of n pairs with these parameters runs."""
+    sm = _sm(score_matrix)
+    name, per_wave = ctypes.create_string_buffer(96), ctypes.c_int()
+    _check(load().swmi_score_kernel_for_batch(n, sm.ctypes.data, _gap(gap_penalty), mode, name, 96, ctypes.byref(per_wave)))
+    return name.value.decode(), per_wave.value
 
 
 def device_info():

@@ -38,8 +38,8 @@ while time.time() < t_end:
     elif kind == 1: sm = swmi.match_matrix(1, -1); gap = 1
     elif kind == 2: sm = rng.integers(-128, 128, 16).astype(np.int8); gap = int(rng.integers(0, 128))
     else: sm = rng.integers(-12, 13, 16).astype(np.int8); gap = int(rng.integers(0, 9))
-    L = [4, 8, 16, 2, 32, 64][rounds % 6]
-    swmi.set_schedule(L, int(rng.integers(0, 2)))
+    L = [4, 4, 8, 4, 16, 2, 4, 32, 64][rounds % 9]      # L = 4 (the packed kernel unless a flag says otherwise) meets every parameter family
+    swmi.set_schedule(L, int((0, 0, 1, 8)[int(rng.integers(0, 4))]))
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, seed, first, st)
     if rounds % 3 == 1:      # make half of the batch related pairs (mutated copies) so that long alignments occur
         m = torch.rand(n * 128, device="cuda") < 0.85

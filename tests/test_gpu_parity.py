@@ -10,9 +10,10 @@ from conftest import match_matrix
 pytestmark = pytest.mark.gpu
 
 # (lanes per alignment, flags): flags 0 = gap-folded cell when the matrix allows it, 1 = general cell,
-# 2 = 16-bit-max cell, 4 = LDS score-lookup kernel (falls back to the v_dot4 kernel where it does not apply)
+# 2 = 16-bit-max cell, 4 = LDS score-lookup kernel (falls back to the v_dot4 kernel where it does not apply),
+# 8 = never the packed kernel (which (4, 0) picks by itself for parameter sets whose folded scores are all >= 0)
 SCHEDULES = [(64, 0), (64, 1), (32, 0), (32, 3), (16, 0), (16, 1), (16, 4), (8, 0), (8, 1), (8, 2), (8, 3), (8, 4),
-             (4, 0), (4, 1), (4, 2), (4, 4), (2, 0), (2, 1)]
+             (4, 0), (4, 1), (4, 2), (4, 4), (4, 8), (2, 0), (2, 1)]
 
 
 @pytest.mark.parametrize("lanes,flags", SCHEDULES)
@@ -49,6 +50,42 @@ def test_random_parameters_vs_oracle(gpu, oracle, seed):
     sm = rng.integers(lo, hi + 1, 16).astype(np.int8)
     for gap in (0, 1, int(rng.integers(2, 127)), 127):
         assert np.array_equal(gpu.score_batch(a, b, sm, gap), oracle.batch(a, b, sm, gap)), (sm, gap)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_packed_kernel_for_non_negative_folded_scores(gpu, oracle, seed):
+    """sw128_pk_kernel (row N2: (1,-1,1) and every other matrix with min(sm) + gap >= 0): two alignments per register,
+    v_perm lookup, v_pk_maximum3_f16 as a packed integer max.  Against the oracle and against the int32 kernel (flag 8),
+    through all three entry shapes, with ragged batch sizes (an odd last pair leaves half a register idle)."""
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(40000, 70000)) | 1 if seed % 2 else int(rng.integers(40000, 70000)) & ~1
+    a = rng.integers(0, 4, (n, 128), dtype=np.uint8)
+    b = rng.integers(0, 4, (n, 128), dtype=np.uint8)
+    sim = rng.random(n) < 0.6
+    keep = rng.random((n, 128)) < 0.9
+    b[sim] = np.where(keep[sim], np.roll(a, int(rng.integers(0, 4)), axis=1)[sim], b[sim])
+    b[: n // 50] = a[: n // 50]                      # some identical pairs: the largest scores the parameters allow
+    gap = int((0, 1, 1, 3, 17, 60, 127, 2)[seed])
+    if seed == 0:
+        sm = match_matrix(1, -1)                     # SmithWaterman_8bit111simd / _8b111x32 (source.cpp:1105-1522)
+        gap = 1
+    elif seed == 1:
+        sm = np.full(16, 127, np.int8)               # the largest scores: every cell 127, gap 0 -> 16256
+        gap = 0
+    else:
+        sm = rng.integers(-gap, 127 - gap + 1, 16).astype(np.int8)      # min(sm) + gap >= 0, max(sm) + gap <= 127
+    want = oracle.batch(a, b, sm, gap)
+    gpu.set_schedule(4, 0)
+    try:
+        got = gpu.score_batch(a, b, sm, gap)
+        assert np.array_equal(got, want), (sm, gap)
+        assert np.array_equal(gpu.score_batch_packed(oracle.pack(a), oracle.pack(b), sm, gap), want)
+        assert np.array_equal(gpu.score_one_vs_many(a, b[0], sm, gap), oracle.batch(a, np.repeat(b[:1], n, axis=0), sm, gap))
+        gpu.set_schedule(4, 8)                       # the same parameters on the int32 kernel
+        assert np.array_equal(gpu.score_batch(a, b, sm, gap), want)
+    finally:
+        gpu.set_schedule(0, 0)
 
 
 def test_domain_edges(gpu, oracle):

@@ -17,7 +17,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = "sw128_kernel"
+KERNEL = "sw128_"          # sw128_pk_kernel (what the default schedule runs for large batches) or sw128_kernel
 
 
 def counter_rows(sub):
@@ -64,11 +64,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 try:
     import re
     import isa_census
-    targs = re.search(r"sw128_kernel<([^>]*)>", summary.get("kernel", ""))
+    targs = re.search(r"(sw128_\w*kernel)<([^>]*)>", summary.get("kernel", ""))
     if targs:
-        vals = [{"true": "1", "false": "0"}.get(v.strip(), v.strip()) for v in targs.group(1).split(",")]
-        readable = "sw128_kernel<%s>" % ",".join(vals)
-        c = isa_census.census_for("^" + re.escape(readable) + "$", marker_op="v_dot4_i32_i8")
+        vals = [{"true": "1", "false": "0"}.get(v.strip(), v.strip()) for v in targs.group(2).split(",")]
+        readable = "%s<%s>" % (targs.group(1), ",".join(vals))
+        c = isa_census.census_for("^" + re.escape(readable) + "$", marker_op="v_perm_b32" if "pk" in readable else "v_dot4_i32_i8")
         summary["kernel_readable"] = readable
         summary["kernel_code_sha256"] = c[readable]["code_sha256"]
 except Exception as e:      # noqa: BLE001
