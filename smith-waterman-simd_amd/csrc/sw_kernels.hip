@@ -431,6 +431,10 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     }
     __builtin_amdgcn_s_setprio(2);
 
+    // The integers below 1024 are half-precision DENORMALS as bit patterns: make sure the wavefront keeps them (MODE.FP_DENORM
+    // bits 7:6 = f16 / f64 input and output denormals allowed -- hipcc's default, set here so that no compile flag can undo it).
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
+
     uint32_t h[R];                          // H(row i, previous column): X in the low half, Y in the high half
 #pragma unroll
     for (int i = 0; i < R; ++i) h[i] = 0;
