@@ -331,44 +331,72 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 // such integers order exactly like the IEEE half-precision numbers with the same bit patterns (denormals included; hipcc
 // kernels keep f16 denormals; tools/experiments/pk_max3_probe.hip checks the claim on 1M random triples).  Two cells' max3
 // in one half-rate instruction (v_max3_i32 does one) is what makes 16-bit packing pay on this VALU -- with v_pk_max_i16
-// alone it only ties with the int32 cell.  Every value of the gap-folded recurrence can be kept
-// non-negative and below 16 512:
+// alone it only ties with the int32 cell.  Every value of the gap-folded recurrence is kept
+// non-negative and below 16 768 by working on values SHIFTED by a bias Q:
 //     sc = s + gap + Q >= 0            (Q = max(0, -(min s + gap)); one byte: s + gap + Q <= 255 for every int8 matrix)
-//     t  = (H(i-1,j-1) + sc) -sat Q    (the folded diagonal term, floored at 0: a negative t never wins the max below)
-//     x  = max3(left, up, t),   H = x -sat gap
-// When every s + gap is already >= 0 -- (1,-1,1), the parameters of SmithWaterman_8bit111simd / _8b111x32
-// (source.cpp:1105-1522), are the model case -- Q = 0 and the second subtraction disappears (BIAS = false).
+//     t  = H(i-1,j-1) + sc             (the folded diagonal term + Q: a plain add, never negative)
+//     x  = max3(left + Q, up + Q, t)   (= the unshifted x + Q)
+//     H  = x -sat (gap + Q),   H + Q = H + Q
+// The previous column is held twice, as H (what t starts from) and as H + Q (what `left` and `up` are): both additions are
+// 32-bit FULL-RATE v_add_u32 on the packed pair -- no half ever carries into the other -- instead of a second saturating
+// packed subtraction for t.  When every s + gap is already >= 0 -- (1,-1,1), the parameters of SmithWaterman_8bit111simd /
+// _8b111x32 (source.cpp:1105-1522), are the model case -- Q = 0, the two copies are one and the "+ Q" disappears
+// (BIAS = false).
 //   * one VGPR holds the SAME row of TWO alignments (low / high half), so there is no dependency inside a pair and the
 //     two alignments share every instruction; a lane group of L = 4 lanes walks two alignments, a wavefront 32;
-//   * score lookup for both halves = ONE v_perm_b32: its 8 source bytes are the 4 scores of the row for alignment X and
-//     for alignment Y, its selector -- staged per column in LDS in place of the one-hot -- picks score[X][base of X's
-//     column] into byte 0 and score[Y][base of Y's column] into byte 2 (zero bytes between; pad columns select zeros);
-//   * t = v_pk_add_u16 (+ v_pk_sub_u16 clamp), x = v_pk_maximum3_f16, H = v_pk_sub_u16 clamp, running best =
-//     v_pk_maximum3_f16 over two cells: 18 (Q = 0) / 22 issue cycles per 2 cells = 9 / 11 per cell, every instruction in
-//     the half-rate class -- which, unlike the int32 cell's full-rate third, issues at its nominal rate at 4 wavefronts per
-//     SIMD.
+//   * score lookup for both halves = ONE v_perm_b32: its 8 source bytes are the score tables of the CURRENT COLUMN of
+//     alignment X and of alignment Y (4 bytes each: the column's base against the four row bases, fetched per step from a
+//     5-entry table in LDS through the per-column offsets staged there), its selector is a per-ROW register that picks
+//     table[X][base of X's row] into byte 0 and table[Y][base of Y's row] into byte 2 (zero bytes between; pad columns
+//     fetch the all-zero table).  A row costs ONE register for the lookup (round 2's first version kept the two row tables
+//     in registers, 2 per row, with the selector per column), which is what makes room for the second copy of H;
+//   * per row and alignment pair: v_perm_b32, v_add_u32, v_pk_maximum3_f16, v_pk_sub_u16 clamp, (v_add_u32,) and half a
+//     v_pk_maximum3_f16 for the running best: 16 (Q = 0) / 18 nominal issue cycles per 2 cells;
+//   * issued in a hand-chosen order (volatile asm, see "Order of issue" in the kernel).
 // Same anti-diagonal pipeline, DPP hand-over and pad-column argument as sw128_kernel (header of this file).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));    // (not volatile: a pure function, freely scheduled)
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+// The cell's instructions as VOLATILE asm: hipcc keeps volatile statements in program order, which is how the cell is
+// scheduled by hand in sw128_pk_kernel ("Order of issue").  Operands are ordinary values, so register allocation, the
+// s_waitcnt for LDS loads and the wait states between a packed result and its consumer stay with the compiler.
+__device__ __forceinline__ uint32_t v_pk_max3(uint32_t a, uint32_t b, uint32_t c)
 {
-    const u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);                        // v_pk_add_u16
-    return __builtin_bit_cast(uint32_t, r);
+    uint32_t r;
+    asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
+__device__ __forceinline__ uint32_t v_pk_sub_sat(uint32_t a, uint32_t b_uniform)
 {
-    const u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));   // v_pk_sub_u16 ... clamp
-    return __builtin_bit_cast(uint32_t, r);
+    uint32_t r;
+    asm volatile("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t v_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t v_add_uniform(uint32_t a_uniform, uint32_t b)
+{
+    uint32_t r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    uint32_t r;
+    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "v"(sel));
+    return r;
 }
 
+// amdgpu_waves_per_eu(3): 144 VGPRs in the bias form (three copies of 32 rows: selectors, H + Q, H); a budget of 128 spills
 template <int MODE, bool BIAS>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(3)))
 sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
                 uint32_t n, SmRows rows /* s + gap + Q, every byte in [0, 255] */, int gap, int q)
 {
@@ -379,10 +407,14 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     constexpr int S = kSeqLen + 2 * PAD;
     constexpr int T2 = (kSeqLen + L) / 2;
     constexpr int NW = R / 4;
-    constexpr uint32_t kZeroSel = 0x0C0C0C0Cu;              // v_perm selector 0x0C = constant 0x00
+    constexpr uint32_t kPadCode = 16u | (16u << 16);        // both halves point at the all-zero table
 
-    __shared__ uint32_t lds_sel[kWavesPerBlock][G * S];     // per column of an alignment pair: the v_perm selector
-    __shared__ uint32_t lds_rows[kWavesPerBlock][4];
+    // per column of an alignment pair: the LDS byte offsets (into lds_tab) of the column's score table for X (low half) and
+    // for Y (high half)
+    __shared__ uint32_t lds_col[kWavesPerBlock][G * S];
+    // lds_tab[b], b < 4: the scores of column base b against the four row bases, one per byte (the transposed matrix);
+    // lds_tab[4] = 0 for pad columns.  The same for every wavefront of the block, which all write it (identical values).
+    __shared__ uint32_t lds_tab[8];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -407,81 +439,121 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
         load_bases<R>(seq2s + (MODE == 2 ? (size_t)0 : (size_t)py * kSeqLen) + j * R, by);
     }
 
-    if (lane < 4) lds_rows[wv][lane] = rows.r[lane];
-    uint32_t *prof = &lds_sel[wv][g * S];
+    if (lane < 5) {
+        uint32_t c = 0;
+        if (lane < 4) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) c |= ((rows.r[a] >> (8 * lane)) & 0xFFu) << (8 * a);
+        }
+        lds_tab[lane] = c;
+    }
+    uint32_t *prof = &lds_col[wv][g * S];
     for (int k = j; k < PAD; k += L) {
-        prof[k] = kZeroSel;
-        prof[PAD + kSeqLen + k] = kZeroSel;
+        prof[k] = kPadCode;
+        prof[PAD + kSeqLen + k] = kPadCode;
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const uint32_t cx = (bx[i / 4] >> (8 * (i % 4))) & 3u, cy = (by[i / 4] >> (8 * (i % 4))) & 3u;
-        // byte 0 <- source byte cx (X's row scores), byte 2 <- source byte 4 + cy (Y's row scores), bytes 1 and 3 <- 0x00
-        prof[PAD + j * R + i] = cx | 0x0C00u | ((4u + cy) << 16) | 0x0C000000u;
+        prof[PAD + j * R + i] = (cx * 4u) | (cy * 4u) << 16;
+    }
+    // v_perm selector of row i: byte 0 <- byte (base of X's row) of X's column table, byte 2 <- byte (base of Y's row) of
+    // Y's column table (source bytes 4..7), bytes 1 and 3 <- 0x00 (selector 0x0C)
+    uint32_t rsel[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const uint32_t ra = (ax[i / 4] >> (8 * (i % 4))) & 3u, rb = (ay[i / 4] >> (8 * (i % 4))) & 3u;
+        rsel[i] = ra | 0x0C040C00u | (rb << 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    uint32_t tx[R], ty[R];                  // folded scores (4 bytes, one per column base) of row i for X / for Y
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        tx[i] = lds_rows[wv][(ax[i / 4] >> (8 * (i % 4))) & 3u];
-        ty[i] = lds_rows[wv][(ay[i / 4] >> (8 * (i % 4))) & 3u];
-    }
     __builtin_amdgcn_s_setprio(2);
 
     // The integers below 1024 are half-precision DENORMALS as bit patterns: make sure the wavefront keeps them (MODE.FP_DENORM
     // bits 7:6 = f16 / f64 input and output denormals allowed -- hipcc's default, set here so that no compile flag can undo it).
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
 
-    uint32_t h[R];                          // H(row i, previous column): X in the low half, Y in the high half
-#pragma unroll
-    for (int i = 0; i < R; ++i) h[i] = 0;
-    uint32_t best = 0, u0 = 0, u1 = 0;
-    const uint32_t gap2 = (uint32_t)gap | ((uint32_t)gap << 16);
+    // Two copies of the previous column, X in the low half and Y in the high half of every register:
+    //   hq[i] = H(row i) + Q   what `left` and `up` are (the max3 runs on values shifted by Q, which keeps the diagonal term
+    //                          t = H(i-1,j-1) + (s + gap + Q) non-negative without a second saturating subtraction)
+    //   hu[i] = H(row i)       what the diagonal term starts from
+    // Adding Q is a plain 32-bit add on the packed pair: every half stays in [0, 0x7C00), so nothing carries from the low half
+    // into the high one.  With Q = 0 (BIAS = false) the two copies are one.
+    const uint32_t gq2 = (uint32_t)(gap + q) | ((uint32_t)(gap + q) << 16);
     const uint32_t q2 = (uint32_t)q | ((uint32_t)q << 16);
+    uint32_t hq[R], hu_[R];                 // (hu_ is dead code when Q = 0)
+#pragma unroll
+    for (int i = 0; i < R; ++i) { hq[i] = q2; hu_[i] = 0; }
+    uint32_t best = 0, u0 = q2, u1 = q2;
     const int group_mask = keep(j == 0 ? 0 : -1);
-    const uint32_t *col = prof + PAD - j;   // col[t] = selector of column t - j
+    const uint32_t edge = (uint32_t)keep((int)(j == 0 ? q2 : 0u));   // above the first row of an alignment: H = 0
+    const uint32_t *col = prof + PAD - j;   // col[t] = table offsets of column t - j
 
-    auto step = [&](uint32_t sel, uint32_t up, uint32_t diag) {
-        uint32_t dprev = diag, xprev = 0;
+    // Order of issue.  A wavefront issues in order and a dependent instruction waits for its producer, so the row is laid
+    // out with an independent instruction between any two dependent ones: the lookup (P) runs two rows ahead and the
+    // diagonal add (T) one row ahead of the chain  M (max3) -> S (saturating subtract) [-> A (add Q)] -> M of the next row.
+    // Left to the compiler (lookup, add, max3, subtract, add back to back) the same instructions run 8 % slower; of the
+    // orders tried, M T S P A B is the fastest (tools/experiments/README.md).
+    auto step = [&](uint32_t cx, uint32_t cy, uint32_t up, uint32_t diag) {
+        uint32_t d0 = diag;
+        if constexpr (BIAS) d0 = diag - q2;                                     // H of the diagonal neighbour of row 0
+        const uint32_t sc0 = v_perm(cy, cx, rsel[0]);
+        uint32_t sc = v_perm(cy, cx, rsel[1]);                                  // scores of row 1
+        uint32_t t = v_add(d0, sc0);                                            // diagonal term of row 0
+        uint32_t xprev = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const uint32_t left = h[i];
-            const uint32_t sc = __builtin_amdgcn_perm(ty[i], tx[i], sel);        // {S0 = Y's scores: bytes 4..7, S1 = X's: bytes 0..3}
-            uint32_t t = pk_add(dprev, sc);
-            if constexpr (BIAS) t = pk_sub_sat(t, q2);
-            const uint32_t x = pk_max3(left, up, t);
-            if (i & 1) best = pk_max3(best, xprev, x);
+            uint32_t sc_next = 0, t_next = 0;
+            const uint32_t h_old = BIAS ? hu_[i] : hq[i];                       // H(row i, previous column)
+            const uint32_t x = v_pk_max3(hq[i], up, t);                         // M_i      x + Q
+            if (i + 1 < R) t_next = v_add(h_old, sc);                           // T_{i+1}  H(i, j-1) + (s + gap + Q)
+            const uint32_t hn = v_pk_sub_sat(x, gq2);                           // S_i      H = (x + Q) -sat (gap + Q)
+            if (i + 2 < R) sc_next = v_perm(cy, cx, rsel[i + 2]);               // P_{i+2}
+            if constexpr (BIAS) {
+                hu_[i] = hn;
+                hq[i] = v_add_uniform(q2, hn);                                  // A_i      H + Q
+            } else {
+                hq[i] = hn;
+            }
+            if (i & 1) best = v_pk_max3(best, xprev, x);                        // B
             xprev = x;
-            const uint32_t hn = pk_sub_sat(x, gap2);
-            h[i] = hn;
-            up = hn;
-            dprev = left;
+            up = hq[i];
+            sc = sc_next;
+            t = t_next;
         }
-        return (uint32_t)from_prev_lane<L>((int)h[R - 1], group_mask);
+        asm volatile("s_nop 1");            // the DPP below reads a register the asm above wrote: 2 wait states, by hand
+        uint32_t out = (uint32_t)from_prev_lane<L>((int)hq[R - 1], group_mask);
+        if constexpr (BIAS) out |= edge;
+        return out;
+    };
+    auto tables = [&](uint32_t code, uint32_t &cx, uint32_t &cy) {
+        cx = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code & 0xFFFFu));
+        cy = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code >> 16));
     };
 
-    uint32_t e0 = col[0];
+    uint32_t c1 = col[1], x0, y0;
+    tables(col[0], x0, y0);
     for (int t2 = 0; t2 < T2; ++t2) {
-        const uint32_t e1 = col[2 * t2 + 1];
-        const uint32_t e2 = col[2 * t2 + 2];
-        u1 = step(e0, u0, u1);
-        u0 = step(e1, u1, u0);
-        e0 = e2;
+        const uint32_t c2 = col[2 * t2 + 2], c3 = col[2 * t2 + 3];
+        uint32_t x1, y1, x2, y2;
+        tables(c1, x1, y1);
+        u1 = step(x0, y0, u0, u1);
+        tables(c2, x2, y2);
+        u0 = step(x1, y1, u1, u0);
+        x0 = x2; y0 = y2; c1 = c3;
     }
 
-    // reduce over the L lanes of the group (packed), then unfold the gap: the maximum was tracked on x = H + gap
+    // reduce over the L lanes of the group (packed), then unfold: the maximum was tracked on x + Q = H + gap + Q
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
         best = pk_max3(best, other, other);
     }
-    const int bx_score = (int)(best & 0xFFFFu), by_score = (int)(best >> 16);
+    const int bx_score = (int)(best & 0xFFFFu), by_score = (int)(best >> 16), gq = gap + q;
     if (j == 0) {
-        if (live_x) scores[px] = bx_score > gap ? bx_score - gap : 0;
-        if (live_y) scores[py] = by_score > gap ? by_score - gap : 0;
+        if (live_x) scores[px] = bx_score > gq ? bx_score - gq : 0;
+        if (live_y) scores[py] = by_score > gq ? by_score - gq : 0;
     }
 }
 

@@ -61,7 +61,7 @@ int main()
     CHECK(swmi_score_batch_device((void *)8, (void *)16, 1, sm, 15, (void *)32, nullptr) == SWMI_ERR_ALIGNMENT);
     CHECK(swmi_semiglobal_xdrop_device((void *)16, (void *)16, 1, (void *)16, (void *)24, 8, (void *)16, nullptr) == SWMI_ERR_ALIGNMENT);
     CHECK(swmi_set_schedule(3, 0) == SWMI_ERR_INVALID_ARGUMENT);
-    CHECK(swmi_set_schedule(4, 8) == SWMI_ERR_INVALID_ARGUMENT);
+    CHECK(swmi_set_schedule(4, 16) == SWMI_ERR_INVALID_ARGUMENT);     // flags 1, 2, 4, 8 exist
     CHECK(swmi_use_gpu(-1) == SWMI_ERR_INVALID_ARGUMENT);
     CHECK(swmi_queue_destroy(nullptr) == SWMI_OK);
     CHECK(swmi_sharded_destroy(nullptr) == SWMI_OK);

@@ -18,21 +18,22 @@ pytestmark = pytest.mark.skipif(not (os.path.exists("/opt/rocm/lib/llvm/bin/llvm
 
 def test_headline_kernel_census():
     import isa_census
-    # what the default schedule runs for a large batch with the harness parameters (10, -30, 15): the packed kernel with its
-    # bias subtraction (sw128_pk_kernel<mode 0, BIAS 1>)
+    # what the default schedule runs for a large batch with the harness parameters (10, -30, 15): the packed kernel in its
+    # bias form (sw128_pk_kernel<mode 0, BIAS 1>)
     found = isa_census.census_for(r"^sw128_pk_kernel<0,1>$", marker_op="v_perm_b32")
     assert list(found) == ["sw128_pk_kernel<0,1>"]
     c = found["sw128_pk_kernel<0,1>"]
     ops = c["main_loop"]["by_op"]
-    # two anti-diagonal steps x 32 rows, two alignments per register: per PAIR of cells one v_perm (lookup), one add, two
-    # saturating subtractions (bias, gap), one three-input max + half of one for the running best
-    assert ops["v_perm_b32"] == 64 and ops["v_pk_add_u16"] == 64 and ops["v_pk_sub_u16"] == 128 and ops["v_pk_maximum3_f16"] == 96
+    # two anti-diagonal steps x 32 rows, two alignments per register: per PAIR of cells one v_perm (lookup), two full-rate
+    # 32-bit adds (diagonal term, H + Q), one saturating subtraction, one three-input max + half of one for the running best
+    assert ops["v_perm_b32"] == 64 and ops["v_pk_sub_u16"] == 64 and ops["v_pk_maximum3_f16"] == 96
+    assert 128 <= ops["v_add_u32"] <= 132 and "v_pk_add_u16" not in ops
     assert c["main_loop"]["by_class"].get("vmem", 0) == 0 and c["main_loop"]["unmeasured_valu"] == 0
     assert c["main_loop_conditional"]["instructions"] == 0
     assert len(c["code_sha256"]) == 16
-    # without the bias (every folded score >= 0, e.g. (1,-1,1)): one subtraction per pair fewer
+    # without the bias (every folded score >= 0, e.g. (1,-1,1)): one add per pair fewer
     ops0 = isa_census.census_for(r"^sw128_pk_kernel<0,0>$", marker_op="v_perm_b32")["sw128_pk_kernel<0,0>"]["main_loop"]["by_op"]
-    assert ops0["v_pk_sub_u16"] == 64 and ops0["v_pk_maximum3_f16"] == 96
+    assert ops0["v_pk_sub_u16"] == 64 and ops0["v_pk_maximum3_f16"] == 96 and 64 <= ops0["v_add_u32"] <= 68
     # the int32 kernel (schedule flag 8, and every L other than 4)
     ci = isa_census.census_for(r"^sw128_kernel<4,1,0,0>$", marker_op="v_dot4_i32_i8")["sw128_kernel<4,1,0,0>"]["main_loop"]["by_op"]
     assert ci["v_dot4_i32_i8"] == 64 and ci["v_sub_u32"] == 64 and 64 <= ci["v_max3_i32"] <= 96
@@ -62,9 +63,10 @@ def test_issue_bound_is_a_utilisation():
     assert r["census"]["valu_instructions_per_wavefront"] == 14247       # x 65,536 = 933.7 M: SQ_INSTS_VALU read 933.9 M
     ideal_ms = r["frac"] * 1.4975
     assert bench.issue_bound(r"^sw128_kernel<4,1,0,0>$", 66, 65536, ideal_ms, marker=("v_dot4_i32_i8", 64))["frac"] == pytest.approx(1.0, abs=2e-3)
-    # the packed kernel: 32 alignments per wavefront -> 32,768 wavefronts; 1.307 ms measured
-    rp = bench.issue_bound(r"^sw128_pk_kernel<0,1>$", 66, 32768, 1.307, marker=("v_perm_b32", 64))
-    assert 0.9 < rp["frac"] <= 1.0
+    # the packed kernel: 32 alignments per wavefront -> 32,768 wavefronts; 1.17 ms measured.  A third of its instructions
+    # are full-rate adds, which only reach their 2-cycle rate when two wavefronts present one at the same time
+    rp = bench.issue_bound(r"^sw128_pk_kernel<0,1>$", 66, 32768, 1.17, marker=("v_perm_b32", 64))
+    assert 0.8 < rp["frac"] <= 1.0
     # unrolled instantiations: the marker count says by how much (L = 64 is unrolled by four)
     r64 = bench.issue_bound(r"^sw128_kernel<64,1,0,0>$", 96, 1 << 20, 2.66, marker=("v_dot4_i32_i8", 4))
     assert r64["census"]["main_loop_trips"] == 24 and 0.85 < r64["frac"] < 1.0
