@@ -360,43 +360,94 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// The cell's instructions as VOLATILE asm: hipcc keeps volatile statements in program order, which is how the cell is
-// scheduled by hand in sw128_pk_kernel ("Order of issue").  Operands are ordinary values, so register allocation, the
-// s_waitcnt for LDS loads and the wait states between a packed result and its consumer stay with the compiler.
-__device__ __forceinline__ uint32_t v_pk_max3(uint32_t a, uint32_t b, uint32_t c)
+// TWO ROWS of the packed cell as one block of assembly, in a hand-chosen order of issue:
+//   * a wavefront issues in order and a dependent instruction waits for its producer, so an independent instruction sits
+//     between any two dependent ones: the lookup (P, v_perm_b32) runs two rows ahead and the diagonal add (T) one row ahead
+//     of the chain  M (max3) -> S (saturating subtract) [-> A (add Q)] -> M of the next row.  That also keeps every
+//     consumer of a packed (VOP3P) result one instruction away from its producer -- the wait state hipcc inserts an s_nop
+//     for when it schedules such code itself;
+//   * an s_nop follows each FULL-RATE add that is followed by a half-rate instruction.  A full-rate instruction fills half
+//     of a 4-cycle issue slot and a second wavefront's full-rate instruction can take the other half; with
+//     its own next instruction ready at once, the wavefront claims the following slot instead and the pairing is lost.
+//     Measured on 1M pairs (bias form): no s_nop 1.254 ms, this placement 1.147 ms, an s_nop after every instruction
+//     1.288 ms; Q = 0 form: 1.046 / 1.002 ms.  (profiles/r02_pk_cell_order_search.txt)
+// Rows i (suffix 0) and i+1 (suffix 1).  in: t = diagonal term of row i, sc = looked-up scores of row i+1, up = H + Q of
+// the row above;  out: t = diagonal term of row i+2, sc = scores of row i+3; hq1 is the next block's `up`.
+// LAST: rows R-2, R-1 -- nothing to look ahead to; s_nop keeps the spacing.
+template <bool BIAS, bool LAST>
+__device__ __forceinline__ void pk_two_rows(uint32_t &hq0, uint32_t &hq1, uint32_t &hu0, uint32_t &hu1, uint32_t &best, uint32_t &t,
+                                            uint32_t &sc, uint32_t up, uint32_t sel2, uint32_t sel3, uint32_t cx, uint32_t cy,
+                                            uint32_t gq2, uint32_t q2)
 {
-    uint32_t r;
-    asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t v_pk_sub_sat(uint32_t a, uint32_t b_uniform)
-{
-    uint32_t r;
-    asm volatile("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(b_uniform));
-    return r;
-}
-__device__ __forceinline__ uint32_t v_add(uint32_t a, uint32_t b)
-{
-    uint32_t r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t v_add_uniform(uint32_t a_uniform, uint32_t b)
-{
-    uint32_t r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel)
-{
-    uint32_t r;
-    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "v"(sel));
-    return r;
+    uint32_t x0, x1, s2;
+    if constexpr (BIAS && !LAST) {
+        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"          // M0   x + Q
+                     "v_add_u32 %[t], %[hu0], %[sc]\n\t"                          // T1   H(row i, previous column) + score
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hu0], %[x0], %[gq] clamp\n\t"                // S0   H = (x + Q) -sat (gap + Q)
+                     "v_perm_b32 %[s2], %[cy], %[cx], %[sel2]\n\t"                // P2
+                     "v_add_u32 %[hq0], %[q], %[hu0]\n\t"                         // A0   H + Q
+                     "s_nop 0\n\t"
+                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"          // M1
+                     "v_add_u32 %[t], %[hu1], %[s2]\n\t"                          // T2
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hu1], %[x1], %[gq] clamp\n\t"                // S1
+                     "v_perm_b32 %[sc], %[cy], %[cx], %[sel3]\n\t"                // P3
+                     "s_nop 0\n\t"
+                     "v_add_u32 %[hq1], %[q], %[hu1]\n\t"                         // A1
+                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]"           // B
+                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [hu0] "+v"(hu0), [hu1] "+v"(hu1), [best] "+v"(best), [t] "+v"(t),
+                       [sc] "+v"(sc), [x0] "=&v"(x0), [x1] "=&v"(x1), [s2] "=&v"(s2)
+                     : [up] "v"(up), [sel2] "v"(sel2), [sel3] "v"(sel3), [cx] "v"(cx), [cy] "v"(cy), [gq] "s"(gq2), [q] "s"(q2));
+    } else if constexpr (BIAS && LAST) {
+        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"
+                     "v_add_u32 %[t], %[hu0], %[sc]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hu0], %[x0], %[gq] clamp\n\t"
+                     "s_nop 0\n\t"
+                     "v_add_u32 %[hq0], %[q], %[hu0]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hu1], %[x1], %[gq] clamp\n\t"
+                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]\n\t"
+                     "v_add_u32 %[hq1], %[q], %[hu1]"
+                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [hu0] "+v"(hu0), [hu1] "+v"(hu1), [best] "+v"(best), [t] "+v"(t),
+                       [x0] "=&v"(x0), [x1] "=&v"(x1)
+                     : [up] "v"(up), [sc] "v"(sc), [gq] "s"(gq2), [q] "s"(q2));
+    } else if constexpr (!LAST) {
+        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"          // M0    (k = 0)
+                     "v_add_u32 %[t], %[hq0], %[sc]\n\t"                          // T1    reads H of row i BEFORE S0 replaces it
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hq0], %[x0], %[gq] clamp\n\t"                // S0
+                     "v_perm_b32 %[s2], %[cy], %[cx], %[sel2]\n\t"                // P2
+                     "s_nop 0\n\t"
+                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"          // M1
+                     "v_add_u32 %[t], %[hq1], %[s2]\n\t"                          // T2
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hq1], %[x1], %[gq] clamp\n\t"                // S1
+                     "v_perm_b32 %[sc], %[cy], %[cx], %[sel3]\n\t"                // P3
+                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]"           // B
+                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [best] "+v"(best), [t] "+v"(t), [sc] "+v"(sc), [x0] "=&v"(x0),
+                       [x1] "=&v"(x1), [s2] "=&v"(s2)
+                     : [up] "v"(up), [sel2] "v"(sel2), [sel3] "v"(sel3), [cx] "v"(cx), [cy] "v"(cy), [gq] "s"(gq2));
+    } else {
+        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"
+                     "v_add_u32 %[t], %[hq0], %[sc]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hq0], %[x0], %[gq] clamp\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_sub_u16 %[hq1], %[x1], %[gq] clamp\n\t"
+                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]"
+                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [best] "+v"(best), [t] "+v"(t), [x0] "=&v"(x0), [x1] "=&v"(x1)
+                     : [up] "v"(up), [sc] "v"(sc), [gq] "s"(gq2));
+    }
 }
 
-// amdgpu_waves_per_eu(3): 144 VGPRs in the bias form (three copies of 32 rows: selectors, H + Q, H); a budget of 128 spills
 template <int MODE, bool BIAS>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4)))
 sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
                 uint32_t n, SmRows rows /* s + gap + Q, every byte in [0, 255] */, int gap, int q)
 {
@@ -490,37 +541,22 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     const uint32_t edge = (uint32_t)keep((int)(j == 0 ? q2 : 0u));   // above the first row of an alignment: H = 0
     const uint32_t *col = prof + PAD - j;   // col[t] = table offsets of column t - j
 
-    // Order of issue.  A wavefront issues in order and a dependent instruction waits for its producer, so the row is laid
-    // out with an independent instruction between any two dependent ones: the lookup (P) runs two rows ahead and the
-    // diagonal add (T) one row ahead of the chain  M (max3) -> S (saturating subtract) [-> A (add Q)] -> M of the next row.
-    // Left to the compiler (lookup, add, max3, subtract, add back to back) the same instructions run 8 % slower; of the
-    // orders tried, M T S P A B is the fastest (tools/experiments/README.md).
     auto step = [&](uint32_t cx, uint32_t cy, uint32_t up, uint32_t diag) {
         uint32_t d0 = diag;
         if constexpr (BIAS) d0 = diag - q2;                                     // H of the diagonal neighbour of row 0
-        const uint32_t sc0 = v_perm(cy, cx, rsel[0]);
-        uint32_t sc = v_perm(cy, cx, rsel[1]);                                  // scores of row 1
-        uint32_t t = v_add(d0, sc0);                                            // diagonal term of row 0
-        uint32_t xprev = 0;
+        uint32_t t = d0 + __builtin_amdgcn_perm(cy, cx, rsel[0]);               // diagonal term of row 0
+        uint32_t sc = __builtin_amdgcn_perm(cy, cx, rsel[1]);                   // scores of row 1
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            uint32_t sc_next = 0, t_next = 0;
-            const uint32_t h_old = BIAS ? hu_[i] : hq[i];                       // H(row i, previous column)
-            const uint32_t x = v_pk_max3(hq[i], up, t);                         // M_i      x + Q
-            if (i + 1 < R) t_next = v_add(h_old, sc);                           // T_{i+1}  H(i, j-1) + (s + gap + Q)
-            const uint32_t hn = v_pk_sub_sat(x, gq2);                           // S_i      H = (x + Q) -sat (gap + Q)
-            if (i + 2 < R) sc_next = v_perm(cy, cx, rsel[i + 2]);               // P_{i+2}
+        for (int i = 0; i < R; i += 2) {
             if constexpr (BIAS) {
-                hu_[i] = hn;
-                hq[i] = v_add_uniform(q2, hn);                                  // A_i      H + Q
+                if (i + 2 < R) pk_two_rows<true, false>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, rsel[i + 2], rsel[i + 3], cx, cy, gq2, q2);
+                else           pk_two_rows<true, true>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, 0, 0, cx, cy, gq2, q2);
             } else {
-                hq[i] = hn;
+                uint32_t none0 = 0, none1 = 0;      // Q = 0: H + Q and H are the same registers
+                if (i + 2 < R) pk_two_rows<false, false>(hq[i], hq[i + 1], none0, none1, best, t, sc, up, rsel[i + 2], rsel[i + 3], cx, cy, gq2, q2);
+                else           pk_two_rows<false, true>(hq[i], hq[i + 1], none0, none1, best, t, sc, up, 0, 0, cx, cy, gq2, q2);
             }
-            if (i & 1) best = v_pk_max3(best, xprev, x);                        // B
-            xprev = x;
-            up = hq[i];
-            sc = sc_next;
-            t = t_next;
+            up = hq[i + 1];
         }
         asm volatile("s_nop 1");            // the DPP below reads a register the asm above wrote: 2 wait states, by hand
         uint32_t out = (uint32_t)from_prev_lane<L>((int)hq[R - 1], group_mask);
