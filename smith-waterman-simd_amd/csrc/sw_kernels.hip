@@ -793,6 +793,12 @@ __device__ __forceinline__ int above_minus(int v, int ext)
 
 // kI16: every H of the alignment stays below 2^15 (len * max score < 32768, decided on the host), so the two maxes that
 // form the values handed to the neighbours run as full-rate v_max_i16 (v_max_i32 is half rate on gfx950).
+// s_nop after the full-rate instruction that is followed by a half-rate one (the packed kernel's finding):
+// bit 0 = after the plain saturating subtraction, bit 3 = after the second v_max_i16.  1.578 -> 1.538 ms at 65 536 x 1024.
+#ifndef SWMI_BA_NOPS
+#define SWMI_BA_NOPS 9
+#endif
+#define BA_NOP(bit, v) do { if constexpr ((SWMI_BA_NOPS >> (bit)) & 1) asm volatile("s_nop 0" : "+v"(v)); } while (0)
 template <bool kOpenGeExt, bool kI16>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
@@ -852,24 +858,32 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
         auto pair_of_steps = [&](int b_next) {
             {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
                 const int e = below_minus(me1, ext_v);
-                const int f = sat_sub<false>(mf1, gap_ext);
+                int f = sat_sub<false>(mf1, gap_ext);
+                BA_NOP(0, f);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
                 const int tf = t > f ? t : f;
                 h0 = tf > e ? tf : e;           // v_max3_i32; >= 0 because f >= 0
-                const int hm = sat_sub<false>(h0, oe);
+                int hm = sat_sub<false>(h0, oe);
+                BA_NOP(1, hm);
                 me0 = vmax<kI16>(e, hm);
+                BA_NOP(2, me0);
                 mf0 = vmax<kI16>(f, hm);
+                BA_NOP(3, mf0);
             }
             b_cur = b_next;
             {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
-                const int e = sat_sub<false>(me0, gap_ext);
+                int e = sat_sub<false>(me0, gap_ext);
+                BA_NOP(0, e);
                 const int f = above_minus(mf0, ext_v);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
                 const int te = t > e ? t : e;
                 h1 = te > f ? te : f;           // >= 0 because e >= 0
-                const int hm = sat_sub<false>(h1, oe);
+                int hm = sat_sub<false>(h1, oe);
+                BA_NOP(1, hm);
                 me1 = vmax<kI16>(e, hm);
+                BA_NOP(2, me1);
                 mf1 = vmax<kI16>(f, hm);
+                BA_NOP(3, mf1);
             }
             const int hb = h0 > h1 ? h0 : h1;
             best = best > hb ? best : hb;
