@@ -83,10 +83,11 @@ SmRows pack_rows(const int8_t *sm, int add)
 namespace {
 // Lanes per alignment when the caller has not fixed a schedule: L = 4 (32 rows per lane) issues the fewest instructions
 // per cell and wins once the batch fills the chip; a small batch wants many lanes per alignment instead -- a single pair
-// takes 6 us with L = 64 and 42 us with L = 4 (tools/small_batch_schedule.py, profiles/r01_small_batch_schedule.txt).
+// takes 6 us with L = 64 and 62 us with the packed L = 4 kernel, which holds 32 alignments per wavefront and draws level
+// with L = 16 at 32 768 pairs (tools/small_batch_schedule.py, profiles/r02_small_batch_schedule.txt).
 int auto_lanes(size_t n)
 {
-    return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 20480 ? 16 : 4;
+    return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 32768 ? 16 : 4;
 }
 int resolve_lanes(uint64_t schedule, size_t n)
 {
