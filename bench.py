@@ -492,14 +492,18 @@ def sw128_roofline(swmi, P, sched_lanes, sched_flags, mode, kernel_ms, match, mi
         kernel, per_wave = swmi.score_kernel_for_batch(P, swmi.match_matrix(match, mismatch), gap, mode_id)
     finally:
         swmi.set_schedule(*cur)
-    packed_kernel = kernel.startswith("sw128_pk_kernel")
-    lanes = 4 if packed_kernel else int(re.search(r"<(\d+)", kernel).group(1))
+    packed_kernel = kernel.startswith("sw128_pk_kernel")          # sw128_pk_kernel<MODE,BIAS> (L = 4) or <MODE,BIAS,L>
+    if packed_kernel:
+        targs = re.search(r"<([\d,]+)>", kernel).group(1).split(",")
+        lanes = int(targs[2]) if len(targs) > 2 else 4
+    else:
+        lanes = int(re.search(r"<(\d+)", kernel).group(1))
     trips = (128 + lanes) // 2                   # T2 of the scorers: pairs of anti-diagonal steps
     waves = (P + per_wave - 1) // per_wave
     kernel_s = kernel_ms * 1e-3
-    # what marks one source iteration in the compiled loop: one v_perm per PAIR of cells (packed kernel: 2 steps x 32 rows),
+    # what marks one source iteration in the compiled loop: one v_perm per PAIR of cells (packed kernel: 2 steps x R rows),
     # one v_dot4 per cell (int32 kernel: 2 steps x R rows)
-    marker = ("v_perm_b32", 64) if packed_kernel else ("v_dot4_i32_i8", 2 * (128 // lanes))
+    marker = ("v_perm_b32" if packed_kernel else "v_dot4_i32_i8", 2 * (128 // lanes))
     roof = issue_bound("^" + re.escape(kernel) + "$", trips, waves, kernel_ms, marker=marker)
     roof["lanes_per_alignment"] = lanes
     bytes_per_alignment = {"pairs": BYTES_PER_ALIGNMENT, "packed": 32 + 32 + 4, "one-vs-many": 128 + 4}[mode]

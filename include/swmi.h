@@ -251,8 +251,9 @@ SWMI_API int swmi_queue_destroy(swmi_queue *q);
  * swmi_get_schedule reports 0 in that case.
  * flags (all give identical scores): bit 0 = never fold the gap into the matrix rows (general cell body);
  * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only);
- * bit 3 = never the packed kernel.  (Without it, L = 4 -- also what the automatic choice resolves to for large batches --
- * runs sw128_pk_kernel: two alignments per register, 16-bit cells, v_pk_maximum3_f16 as a packed integer max; ~1.3x
+ * bit 3 = never the packed kernel.  (Without it, L = 4, 8 and 16 -- what the automatic choice resolves to from 5121 pairs
+ * up -- run sw128_pk_kernel: two alignments per register and L lanes per PAIR of alignments, i.e. 32 / 16 / 8 alignments per
+ * wavefront, 16-bit cells, v_pk_maximum3_f16 as a packed integer max; ~1.3x
  * the int32 kernel in general and ~1.5x when every score_matrix entry + gap_penalty is >= 0, e.g. the (1,-1,1) parameters
  * of the reference's SmithWaterman_8bit111simd, source.cpp:1105-1225.  DESIGN.md section 5.) */
 SWMI_API int swmi_set_schedule(int lanes_per_alignment, unsigned flags);

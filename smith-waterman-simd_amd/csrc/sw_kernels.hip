@@ -446,12 +446,15 @@ __device__ __forceinline__ void pk_two_rows(uint32_t &hq0, uint32_t &hq1, uint32
     }
 }
 
-template <int MODE, bool BIAS>
+// L = 4 (32 rows per lane, 32 alignments per wavefront) is what large batches run; L = 8 and 16 are the same kernel with
+// 16 / 8 rows per lane and 16 / 8 alignments per wavefront, for launches that do not fill the chip at L = 4.
+template <int MODE, bool BIAS, int L>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4)))
 sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
                 uint32_t n, SmRows rows /* s + gap + Q, every byte in [0, 255] */, int gap, int q)
 {
-    constexpr int L = 4, R = kSeqLen / L;   // lanes per pair of alignments, rows per lane
+    static_assert(L == 4 || L == 8 || L == 16, "lanes per pair of alignments");
+    constexpr int R = kSeqLen / L;          // rows per lane (L = lanes per pair of alignments)
     constexpr int G = 64 / L;               // lane groups per wavefront, each walking TWO alignments
     constexpr int A = 2 * G;                // alignments per wavefront
     constexpr int PAD = L + 2;
@@ -1003,12 +1006,12 @@ hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s
     if (blocks > 0x7fffffffull || n > 0xffffffffull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
     const uint32_t n32 = (uint32_t)n;
-    if constexpr (L == 4) {
+    if constexpr (L == 4 || L == 8 || L == 16) {
         if (cfg.use_pk) {                   // two alignments per register (rows = s + gap + pk_bias, one byte each)
-            const size_t waves_pk = (n + 31) / 32;
+            const size_t waves_pk = (n + 2 * A - 1) / (2 * A);
             const dim3 grid_pk((unsigned)((waves_pk + kWavesPerBlock - 1) / kWavesPerBlock));
-            if (cfg.pk_bias) hipLaunchKernelGGL((sw128_pk_kernel<MODE, true>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, cfg.pk_bias);
-            else             hipLaunchKernelGGL((sw128_pk_kernel<MODE, false>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0);
+            if (cfg.pk_bias) hipLaunchKernelGGL((sw128_pk_kernel<MODE, true, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, cfg.pk_bias);
+            else             hipLaunchKernelGGL((sw128_pk_kernel<MODE, false, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0);
             return hipGetLastError();
         }
     }

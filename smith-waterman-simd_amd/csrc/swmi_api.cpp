@@ -83,11 +83,12 @@ SmRows pack_rows(const int8_t *sm, int add)
 namespace {
 // Lanes per alignment when the caller has not fixed a schedule: L = 4 (32 rows per lane) issues the fewest instructions
 // per cell and wins once the batch fills the chip; a small batch wants many lanes per alignment instead -- a single pair
-// takes 6 us with L = 64 and 62 us with the packed L = 4 kernel, which holds 32 alignments per wavefront and draws level
-// with L = 16 at 32 768 pairs (tools/small_batch_schedule.py, profiles/r02_small_batch_schedule.txt).
+// takes 6 us with L = 64 and 62 us with the packed L = 4 kernel.  L = 16, 8 and 4 run the packed kernel (8 / 16 / 32
+// alignments per wavefront); the thresholds are where their measured times cross (tools/small_batch_schedule.py,
+// profiles/r02_small_batch_schedule.txt).
 int auto_lanes(size_t n)
 {
-    return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 32768 ? 16 : 4;
+    return n <= 2048 ? 64 : n <= 5120 ? 32 : n <= 24576 ? 16 : n <= 98304 ? 8 : 4;
 }
 int resolve_lanes(uint64_t schedule, size_t n)
 {
@@ -113,9 +114,11 @@ LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *
         if (v < -128 || v > 127) fold = false;
     }
     cfg.fold_gap = fold;
-    // L = 4 with no A/B variant asked for runs the packed kernel (two alignments per register): its rows hold
+    // L = 4, 8 or 16 with no A/B variant asked for runs the packed kernel (two alignments per register, L lanes per PAIR of
+    // alignments): its rows hold
     // s + gap + Q as unsigned bytes, Q = max(0, -(min s + gap)), which fits one byte for every int8 matrix and gap <= 127
-    cfg.use_pk = cfg.lanes_per_alignment == 4 && !(flags & (swmi::kNoPacked | swmi::kNoGapFold | swmi::kUseI16 | swmi::kUseLut));
+    cfg.use_pk = (cfg.lanes_per_alignment == 4 || cfg.lanes_per_alignment == 8 || cfg.lanes_per_alignment == 16) &&
+                 !(flags & (swmi::kNoPacked | swmi::kNoGapFold | swmi::kUseI16 | swmi::kUseLut));
     cfg.pk_bias = 0;
     if (cfg.use_pk) {
         int lowest = 255;
@@ -444,8 +447,9 @@ int swmi_score_kernel_for_batch(size_t n, const int8_t score_matrix[16], int8_t 
     const int L = cfg.lanes_per_alignment;
     int per_wave = 64 / L;
     if (cfg.use_pk) {
-        snprintf(name, name_len, "sw128_pk_kernel<%d,%d>", mode, cfg.pk_bias ? 1 : 0);
-        per_wave = 32;
+        if (L == 4) snprintf(name, name_len, "sw128_pk_kernel<%d,%d>", mode, cfg.pk_bias ? 1 : 0);
+        else        snprintf(name, name_len, "sw128_pk_kernel<%d,%d,%d>", mode, cfg.pk_bias ? 1 : 0, L);
+        per_wave = 128 / L;
     } else if (cfg.fold_gap && cfg.use_lut && L >= 4 && L <= 16) {
         snprintf(name, name_len, "sw128_lut_kernel<%d,%d>", L, mode);
     } else {

@@ -80,8 +80,9 @@ def test_c_shard_rule_is_the_python_shard_rule(swmi_mod):
 
 def test_kernel_choice_is_reported_without_a_device(swmi_mod):
     """swmi_score_kernel_for_batch: which kernel instantiation a launch runs (what bench.py prices with tools/isa_census.py).
-    Large batches run the packed kernel (two alignments per register), with its bias subtraction only when some folded
-    score s + gap is negative; flag 8 and every other lane count run the int32 kernel; small batches take more lanes."""
+    L = 4, 8 and 16 run the packed kernel (two alignments per register; 32 / 16 / 8 alignments per wavefront), in its bias
+    form only when some folded score s + gap is negative; flag 8 and the other lane counts run the int32 kernel; small batches
+    take more lanes."""
     big = 1 << 20
     swmi_mod.set_schedule(0, 0)
     try:
@@ -90,12 +91,17 @@ def test_kernel_choice_is_reported_without_a_device(swmi_mod):
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 127, mode=1) == ("sw128_pk_kernel<1,0>", 32)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -128), 0, mode=2) == ("sw128_pk_kernel<2,1>", 32)
         assert swmi_mod.score_kernel_for_batch(1000, match_matrix(10, -30), 15) == ("sw128_kernel<64,1,0,0>", 1)
-        assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_kernel<16,1,0,0>", 4)
+        assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,16>", 8)
+        assert swmi_mod.score_kernel_for_batch(50000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,8>", 16)
         swmi_mod.set_schedule(4, swmi_mod.NO_PACKED)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(10, -30), 15) == ("sw128_kernel<4,1,0,0>", 16)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 127) == ("sw128_kernel<4,0,0,0>", 16)   # 127 + 127 does not fold
         swmi_mod.set_schedule(8, 0)
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(1, -1), 1) == ("sw128_pk_kernel<0,0,8>", 16)
+        swmi_mod.set_schedule(8, swmi_mod.NO_PACKED)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(1, -1), 1) == ("sw128_kernel<8,1,0,0>", 8)
+        swmi_mod.set_schedule(0, swmi_mod.NO_PACKED)
+        assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_kernel<16,1,0,0>", 4)
         swmi_mod.set_schedule(4, swmi_mod.USE_LUT)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(1, -1), 1) == ("sw128_lut_kernel<4,0>", 16)
     finally:

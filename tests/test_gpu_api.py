@@ -152,11 +152,11 @@ def test_automatic_schedule_follows_the_batch_size(gpu, oracle):
     """lanes = 0 (default): many lanes per alignment for small batches, L = 4 for large ones; same scores either way."""
     gpu.set_schedule(0, 0)
     assert gpu.get_schedule() == (0, 0)
-    assert [gpu.schedule_for_batch(n) for n in (1, 2048, 2049, 5120, 5121, 32768, 32769, 1 << 20)] == [64, 64, 32, 32, 16, 16, 4, 4]
+    assert [gpu.schedule_for_batch(n) for n in (1, 2048, 2049, 5120, 5121, 24576, 24577, 98304, 98305, 1 << 20)] == [64, 64, 32, 32, 16, 16, 8, 8, 4, 4]
     gpu.set_schedule(8, 0)
     assert gpu.schedule_for_batch(1) == 8 and gpu.schedule_for_batch(1 << 20) == 8
     gpu.set_schedule(0, 0)
     sm = match_matrix(10, -30)
-    for n in (1, 17, 2048, 2049, 5121, 20481, 32769):                  # each side of every threshold, ragged sizes included
+    for n in (1, 17, 2048, 2049, 5121, 24577, 98305):                  # each side of every threshold, ragged sizes included
         a, b = oracle.generate(n, 4242, 77)
         assert np.array_equal(gpu.score_batch(a, b, sm, 15), oracle.batch(a, b, sm, 15)), n

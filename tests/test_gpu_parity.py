@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 # (lanes per alignment, flags): flags 0 = gap-folded cell when the matrix allows it, 1 = general cell,
 # 2 = 16-bit-max cell, 4 = LDS score-lookup kernel (falls back to the v_dot4 kernel where it does not apply),
-# 8 = never the packed kernel (which (4, 0) picks by itself for parameter sets whose folded scores are all >= 0)
-SCHEDULES = [(64, 0), (64, 1), (32, 0), (32, 3), (16, 0), (16, 1), (16, 4), (8, 0), (8, 1), (8, 2), (8, 3), (8, 4),
+# 8 = never the packed kernel (what L = 16, 8 and 4 run when no other flag is set: 8 / 16 / 32 alignments per wavefront)
+SCHEDULES = [(64, 0), (64, 1), (32, 0), (32, 3), (16, 0), (16, 1), (16, 4), (16, 8), (8, 0), (8, 1), (8, 2), (8, 3), (8, 4), (8, 8),
              (4, 0), (4, 1), (4, 2), (4, 4), (4, 8), (2, 0), (2, 1)]
 
 

@@ -118,7 +118,10 @@ def readable(symbol):
         if m:
             if not m.group(2):
                 return name
-            return "%s<%s>" % (name, ",".join(re.findall(r"L[a-z](\d+)E", m.group(2))))
+            args = re.findall(r"L[a-z](\d+)E", m.group(2))
+            if name == "sw128_pk_kernel" and len(args) == 3 and args[2] == "4":
+                args = args[:2]             # <MODE, BIAS, L>: the L = 4 instantiation keeps its two-argument name
+            return "%s<%s>" % (name, ",".join(args))
     return symbol
 
 
