@@ -246,9 +246,9 @@ SWMI_API int swmi_queue_destroy(swmi_queue *q);
  * The reference ships nine schedules of one semantics (simd .. simd9).  So does this
  * library: `lanes_per_alignment` L in {64,32,16,8,4,2} lanes of a 64-lane wavefront walk one
  * alignment's anti-diagonal (each lane owns 128/L consecutive rows); L = 64 is literally
- * "one wavefront per alignment".  0 (the default) lets the library choose by batch size: L = 4 from ~20 000 pairs per
- * launch on (fewest instructions per cell), more lanes per alignment below that (lowest latency: L = 64 up to 2048 pairs);
- * swmi_get_schedule reports 0 in that case.
+ * "one wavefront per alignment".  0 (the default) lets the library choose by batch size: L = 4 from ~100 000 pairs per
+ * launch on (fewest instructions per cell), more lanes per alignment below that (lowest latency: L = 64 up to 2048 pairs,
+ * then 32, 16, 8); swmi_get_schedule reports 0 in that case.
  * flags (all give identical scores): bit 0 = never fold the gap into the matrix rows (general cell body);
  * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only);
  * bit 3 = never the packed kernel.  (Without it, L = 4, 8 and 16 -- what the automatic choice resolves to from 5121 pairs
