@@ -498,7 +498,9 @@ def sw128_roofline(swmi, P, sched_lanes, sched_flags, mode, kernel_ms, match, mi
         lanes = int(targs[2]) if len(targs) > 2 else 4
     else:
         lanes = int(re.search(r"<(\d+)", kernel).group(1))
-    trips = (128 + lanes) // 2                   # T2 of the scorers: pairs of anti-diagonal steps
+    # pairs of anti-diagonal steps in the main loop: the int32 kernel rounds T = 128 + L - 1 up, the packed kernel runs the odd
+    # last step after the loop (the census counts it with the instructions outside the loop)
+    trips = (127 + lanes) // 2 if packed_kernel else (128 + lanes) // 2
     waves = (P + per_wave - 1) // per_wave
     kernel_s = kernel_ms * 1e-3
     # what marks one source iteration in the compiled loop: one v_perm per PAIR of cells (packed kernel: 2 steps x R rows),

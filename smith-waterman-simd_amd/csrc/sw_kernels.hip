@@ -459,7 +459,7 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     constexpr int A = 2 * G;                // alignments per wavefront
     constexpr int PAD = L + 2;
     constexpr int S = kSeqLen + 2 * PAD;
-    constexpr int T2 = (kSeqLen + L) / 2;
+    constexpr int T2 = (kSeqLen + L - 1) / 2;               // T = 128 + L - 1 steps (odd): T2 pairs of steps and one more
     constexpr int NW = R / 4;
     constexpr uint32_t kPadCode = 16u | (16u << 16);        // both halves point at the all-zero table
 
@@ -582,6 +582,7 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
         u0 = step(x1, y1, u1, u0);
         x0 = x2; y0 = y2; c1 = c3;
     }
+    step(x0, y0, u0, u1);                   // step 128 + L - 2, the last lane's last column
 
     // reduce over the L lanes of the group (packed), then unfold: the maximum was tracked on x + Q = H + gap + Q
 #pragma unroll
