@@ -67,6 +67,8 @@ try:
     targs = re.search(r"(sw128_\w*kernel)<([^>]*)>", summary.get("kernel", ""))
     if targs:
         vals = [{"true": "1", "false": "0"}.get(v.strip(), v.strip()) for v in targs.group(2).split(",")]
+        if targs.group(1) == "sw128_pk_kernel" and len(vals) == 3 and vals[2] == "4":
+            vals = vals[:2]                 # <MODE, BIAS, L>: the L = 4 instantiation keeps its two-argument name (tools/isa_census.py)
         readable = "%s<%s>" % (targs.group(1), ",".join(vals))
         c = isa_census.census_for("^" + re.escape(readable) + "$", marker_op="v_perm_b32" if "pk" in readable else "v_dot4_i32_i8")
         summary["kernel_readable"] = readable
