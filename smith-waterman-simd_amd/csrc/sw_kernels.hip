@@ -325,7 +325,7 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 }
 
 
-// ---- packed kernel: two alignments per register, any parameters (L = 4) -----------------------------------------------
+// ---- packed kernel: two alignments per register, any parameters (L = 4, 8, 16) ----------------------------------------
 //
 // gfx950's new v_pk_maximum3_f16 is, for NON-NEGATIVE 16-bit integers below 0x7C00, a packed THREE-INPUT INTEGER MAX:
 // such integers order exactly like the IEEE half-precision numbers with the same bit patterns (denormals included; hipcc
@@ -336,14 +336,14 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 //     sc = s + gap + Q >= 0            (Q = max(0, -(min s + gap)); one byte: s + gap + Q <= 255 for every int8 matrix)
 //     t  = H(i-1,j-1) + sc             (the folded diagonal term + Q: a plain add, never negative)
 //     x  = max3(left + Q, up + Q, t)   (= the unshifted x + Q)
-//     H  = x -sat (gap + Q),   H + Q = H + Q
+//     H  = x -sat (gap + Q)            (and H + Q for the neighbours)
 // The previous column is held twice, as H (what t starts from) and as H + Q (what `left` and `up` are): both additions are
 // 32-bit FULL-RATE v_add_u32 on the packed pair -- no half ever carries into the other -- instead of a second saturating
 // packed subtraction for t.  When every s + gap is already >= 0 -- (1,-1,1), the parameters of SmithWaterman_8bit111simd /
 // _8b111x32 (source.cpp:1105-1522), are the model case -- Q = 0, the two copies are one and the "+ Q" disappears
 // (BIAS = false).
 //   * one VGPR holds the SAME row of TWO alignments (low / high half), so there is no dependency inside a pair and the
-//     two alignments share every instruction; a lane group of L = 4 lanes walks two alignments, a wavefront 32;
+//     two alignments share every instruction; a lane group of L lanes walks two alignments (L = 4: a wavefront 32);
 //   * score lookup for both halves = ONE v_perm_b32: its 8 source bytes are the score tables of the CURRENT COLUMN of
 //     alignment X and of alignment Y (4 bytes each: the column's base against the four row bases, fetched per step from a
 //     5-entry table in LDS through the per-column offsets staged there), its selector is a per-ROW register that picks
@@ -352,7 +352,7 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 //     in registers, 2 per row, with the selector per column), which is what makes room for the second copy of H;
 //   * per row and alignment pair: v_perm_b32, v_add_u32, v_pk_maximum3_f16, v_pk_sub_u16 clamp, (v_add_u32,) and half a
 //     v_pk_maximum3_f16 for the running best: 16 (Q = 0) / 18 nominal issue cycles per 2 cells;
-//   * issued in a hand-chosen order (volatile asm, see "Order of issue" in the kernel).
+//   * issued in a hand-chosen order (pk_two_rows below).
 // Same anti-diagonal pipeline, DPP hand-over and pad-column argument as sw128_kernel (header of this file).
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
 {
