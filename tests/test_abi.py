@@ -93,6 +93,9 @@ def test_kernel_choice_is_reported_without_a_device(swmi_mod):
         assert swmi_mod.score_kernel_for_batch(1000, match_matrix(10, -30), 15) == ("sw128_kernel<64,1,0,0>", 1)
         assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,16>", 8)
         assert swmi_mod.score_kernel_for_batch(50000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,8>", 16)
+        # the automatic choice switches where the measured kernel times cross (profiles/r02_small_batch_schedule.txt)
+        per_wave = [swmi_mod.score_kernel_for_batch(n, match_matrix(10, -30), 15)[1] for n in (2048, 2049, 5120, 5121, 24576, 24577, 98304, 98305)]
+        assert per_wave == [1, 2, 2, 8, 8, 16, 16, 32]
         swmi_mod.set_schedule(4, swmi_mod.NO_PACKED)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(10, -30), 15) == ("sw128_kernel<4,1,0,0>", 16)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 127) == ("sw128_kernel<4,0,0,0>", 16)   # 127 + 127 does not fold
