@@ -16,7 +16,7 @@ enum ScheduleFlags : unsigned {
     kNoGapFold = 1u,   // never use the gap-folded recurrence
     kUseLut = 4u,      // LDS score-lookup kernel (sw128_lut_kernel)
     kUseI16 = 2u,      // compiler-scheduled 16-bit max variant (v_max_i16 is full rate, but see DESIGN.md section 5)
-    kNoPacked = 8u,    // never use the packed kernel (sw128_pk_kernel, what L = 4 runs otherwise): A/B against the int32 cell
+    kNoPacked = 8u,    // never use the packed kernel (sw128_pk_kernel, what L = 4, 8, 16 run otherwise): A/B against the int32 cell
 };
 
 struct LaunchConfig {
@@ -25,7 +25,7 @@ struct LaunchConfig {
     bool use_i16;
     unsigned extra_lds_bytes;  // unused dynamic LDS per workgroup: caps workgroups per CU (occupancy sweep, SWMI_EXTRA_LDS)
     bool use_lut;              // LDS score lookup instead of v_dot4 (gap-folded body only, L in {16, 8, 4})
-    bool use_pk;               // L = 4, no other variant asked for: packed kernel, two alignments per register;
+    bool use_pk;               // L = 4, 8 or 16, no other variant asked for: packed kernel, two alignments per register;
     int pk_bias;               //   rows then hold s + gap + pk_bias (bytes 0..255), pk_bias = max(0, -(min s + gap))
 };
 
