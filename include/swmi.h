@@ -46,7 +46,7 @@ extern "C" {
 
 #define SWMI_SEQ_LEN 128        /* std::array<uint8_t,128>, source.cpp:463-464 */
 #define SWMI_PACKED_LEN 32      /* std::array<uint8_t,32>,  source.cpp:1580     */
-#define SWMI_VERSION 200
+#define SWMI_VERSION 300
 
 enum swmi_status {
     SWMI_OK = 0,
@@ -81,7 +81,12 @@ SWMI_API int swmi_init_all(int n_gpus);
 SWMI_API int swmi_init_devices(const int *devices, int n);
 SWMI_API int swmi_num_gpus(void);                 /* number of contexts (0 before init) */
 SWMI_API int swmi_use_gpu(int index);             /* select the context this thread's single-GPU calls address */
-SWMI_API int swmi_shutdown(void);                 /* must not race with other calls into the library */
+/* Releases every context (streams, staging buffers, workspaces).  Must not race with other calls into the library.
+ * Handles created earlier (swmi_queue, swmi_sharded_batch) stay valid OBJECTS: every call on one returns
+ * SWMI_ERR_NOT_INITIALIZED from now on -- also after a new swmi_init* -- and its *_destroy call still releases what the
+ * handle owns.  Destroy handles before shutting down where you can; you do not have to (a garbage-collected binding cannot
+ * promise the order). */
+SWMI_API int swmi_shutdown(void);
 /* Text of the last error on the calling thread ("" if none). Never NULL. */
 SWMI_API const char *swmi_last_error(void);
 SWMI_API int swmi_version(void);
@@ -98,15 +103,24 @@ SWMI_API int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq
 
 /* The reference's 1M-call loop (source.cpp:3074-3082: `for 1,000,000: score = simd4(a,b,sm,gap)`)
  * as ONE call: pair k is the 128 bytes at seq1s + 128*k and seq2s + 128*k (the per-pair
- * layout of std::array<uint8_t,128>, concatenated).  Host buffers (pageable or pinned); the library works in chunks of
- * 1M pairs on two device buffer sets with a stream each, so that chunk k+1's H2D copy overlaps chunk k's kernel and D2H
- * copy.  The copies are issued straight from the caller's memory (the HIP runtime stages pageable pages itself; an extra
- * copy into library-owned pinned memory measured slower); batches of up to 64 pairs go through a
- * pinned, device-visible buffer instead (no copy commands at all).  Thread-safe: calls on one context serialise.
+ * layout of std::array<uint8_t,128>, concatenated).  Host buffers (pageable or pinned).  The PCIe link bounds this entry
+ * (256 B per pair in, against ~1 ns of kernel time per pair), so the batch goes through the GPU in GRANULES on three device
+ * buffer sets with a stream each: granule k's kernel runs while granule k+1 is being copied in, the granules taper (each is
+ * three quarters of what is left, 1M pairs at most, 16K at least: a 1M-pair batch goes as 768K, 192K, 48K, 16K) so that
+ * almost nothing is left to compute when the last copy ends, and the scores come back in ONE copy per 16M pairs after the
+ * last kernel -- a copy into pageable memory blocks the caller until the stream reaches it, so copying scores back behind
+ * every granule (round 2) serialised copy and kernel.  swmi_host_granules() reports the schedule.  The copies are issued
+ * straight from the caller's memory (the HIP runtime stages pageable pages itself; an extra copy into library-owned pinned
+ * memory measured slower); batches of up to 64 pairs go through a pinned, device-visible buffer
+ * instead (no copy commands at all).  Thread-safe: calls on one context serialise.
  * scores[k] receives what SmithWaterman(seq1_k, seq2_k, score_matrix, gap) returns.
  * n may be 0.  Returns SWMI_OK or a negative swmi_status. */
 SWMI_API int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t n,
                               const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
+
+/* The granules a host batch of n pairs is cut into (the pipeline above), in order; returns how many there are and writes
+ * the first `cap` sizes to granules (NULL to count).  Needs no device. */
+SWMI_API size_t swmi_host_granules(size_t n, size_t *granules, size_t cap);
 
 /* Same contract with all three buffers already resident in device memory (16-byte aligned
  * device pointers; `stream` is a hipStream_t, NULL meaning the HIP null stream as usual).
@@ -171,9 +185,16 @@ SWMI_API int swmi_sharded_scores_host(swmi_sharded_batch *b, int32_t *scores);
 SWMI_API int swmi_sharded_gathered_device(swmi_sharded_batch *b, int index, void **d_scores);
 /* the same vector copied to host memory (synchronous): what GPU `index` holds after the gather */
 SWMI_API int swmi_sharded_gathered_host(swmi_sharded_batch *b, int index, int32_t *scores);
-/* What SWMI_GATHER_ALL runs on for this batch: 2 = RCCL, 1 = peer copies (a GPU bound twice, librccl not loadable, or
- * SWMI_GATHER_BACKEND=p2p), 0 = not decided yet (no SWMI_GATHER_ALL call so far). */
+/* What SWMI_GATHER_ALL runs on for this batch: 2 = RCCL, 1 = peer copies (a GPU bound twice, librccl not loadable,
+ * ncclCommInitAll failed, or SWMI_GATHER_BACKEND=p2p), 0 = not decided yet (no SWMI_GATHER_ALL call so far).  Falling back
+ * to peer copies is not an error (same bytes), but it is never silent: the call that decides leaves the reason in
+ * swmi_last_error() while returning SWMI_OK, and swmi_sharded_gather_note() returns it at any later time ("" while RCCL
+ * is in use or nothing is decided). */
 SWMI_API int swmi_sharded_gather_backend(swmi_sharded_batch *b);
+SWMI_API int swmi_sharded_gather_note(swmi_sharded_batch *b, char *text, size_t text_len);
+/* 1 if librccl can be loaded with every entry point the gather needs, else 0 with the loader's reason in `why`.  Needs no
+ * device.  (The library is dlopen()ed on first use, never linked; SWMI_RCCL_LIB names another file to load.) */
+SWMI_API int swmi_rccl_probe(char *why, size_t why_len);
 /* Measurement: `iters` score calls back to back; kernel_ms[g] = average kernel time of GPU g (HIP events on its stream),
  * gather_ms[g] = average time from the end of GPU g's kernel to the end of its part of the gather, *wall_ms = host wall
  * time per call, everything drained.  kernel_ms / gather_ms have swmi_num_gpus() entries (NULL to skip). */
@@ -266,6 +287,15 @@ SWMI_API int swmi_schedule_for_batch(size_t n);
  * tools and bench.py, which derive the issue-bound fraction from the disassembly of exactly that kernel. */
 SWMI_API int swmi_score_kernel_for_batch(size_t n, const int8_t score_matrix[16], int8_t gap_penalty, int mode,
                                          char *name, size_t name_len, int *alignments_per_wavefront);
+
+/* Self-test of the premise the packed kernel rests on: gfx950's v_pk_maximum3_f16, applied to 16-bit integers in
+ * [0, 0x7C00) held two per register, is a packed THREE-INPUT INTEGER MAX (such integers order like the half-precision
+ * numbers with the same bit patterns; the kernels pin MODE.FP_DENORM so that the patterns below 1024, which are f16
+ * denormals, are kept).  Runs the instruction on EVERY pair (a, b) of that range -- 31744^2 pairs, six operand
+ * arrangements each, the third operand one of the two or a pseudo-random third value -- inside a kernel that sets the
+ * mode exactly as the scoring kernels do, and compares with the integer maximum of each half on the device.
+ * *checked = comparisons made (6 * 31744^2), *mismatches = how many failed (0 on gfx950).  No reference counterpart. */
+SWMI_API int swmi_selftest_pk_max3(unsigned long long *checked, unsigned long long *mismatches);
 
 /* ---- synthetic inputs ----------------------------------------------------
  * Counter-based generator, identical on host and device: pair p, sequence s (0/1), 64-bit

@@ -8,8 +8,9 @@
 //     batches) or in 4 / 2 lanes with 8 / 16 cells each (sg_forward_split_kernel, large batches); cell values stay int32.
 //     The band's direction (right / down) is decided per alignment every round from its two end cells (:1895).  Instead
 //     of the reference's 4 MB table of cell values per alignment (source.cpp:1876) the sweep stores, per round, only what
-//     the traceback needs: a 2-bit predecessor code per cell (diag / up / left in the reference's own tie-break order
-//     :1962-1971) and the row of the band's top cell -- 10 bytes per round instead of 128.
+//     the traceback needs: a 2-bit predecessor TAG per cell (3 diagonal / 2 up / 1 left: the candidate that won the cell's
+//     max, in the reference's own tie-break order :1962-1971) = 8 bytes, and ONE bit for the band's move (right / down);
+//     the row of the band's top cell is rebuilt from the move bits (round - right moves so far = a popcount).
 //   * traceback: follows the codes from the best cell back to (0,0) and returns the positions in ascending order, as the
 //     reference does (:1951-1975): one wavefront per walk (sg_traceback_kernel, small batches) or one lane per walk that
 //     records its moves + a prefix-sum kernel that expands them (sg_walk_lane_kernel, sg_expand_kernel, large batches).
@@ -601,25 +602,31 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
 // Traceback for large batches, two kernels.
 //
 // sg_walk_lane_kernel: one LANE per walk (the wave-per-alignment walker above is bound by the scalar unit: one walk per
-// wavefront, ~40 scalar instructions per step; here 64 walks advance per vector instruction).  Each lane keeps the 64-byte
-// line of codes (8 rounds) and of band rows (32 rounds) it is walking through in LDS.  The 64 walks of a wavefront move in
-// LOCKSTEP BY WINDOW of 8 rounds: all lanes consume window w (each at its own pace, 4..8 steps), then the whole wavefront
-// swaps in the line of window w-1, which was requested before window w was walked.  (Refilling per lane, whenever a walk
-// left its line, made almost every step wait for some lane's load: 64 walks at random phases, one dependent HBM access
-// per ~5 steps each.)  The walk does not write positions -- their index in the ascending list is unknown until (0,0) is
+// wavefront, ~40 scalar instructions per step; here 64 walks advance per vector instruction).  The 64 walks of a wavefront
+// move in LOCKSTEP BY WINDOW of 16 rounds = one 128-byte line of code records per walk: all lanes consume window w (each at
+// its own pace, 8..16 steps) out of LDS, then the whole wavefront swaps in the line of window w-1.  (Refilling per lane,
+// whenever a walk left its line, made almost every step wait for some lane's load: 64 walks at random phases.)
+// The kernel is bound by the latency of those line fetches -- 1024 wavefronts, one per SIMD, are all a 65536-walk batch
+// gives -- so what counts is bytes in flight: THREE windows per walk are requested ahead (three register buffers that
+// rotate through the roles, the loop is unrolled by three; 384 bytes per walk in flight; round 2: 64-byte half lines, one
+// ahead, 3.5 TB/s).  The walk does not write positions -- their index in the ascending list is unknown until (0,0) is
 // reached -- but its moves, 2 bits per step (1 diag, 2 up, 3 left), 8 KB per alignment at most.
 //
 // sg_expand_kernel: one wavefront per alignment turns the moves into the (i, j) list of source.cpp:1951-1975, in
 // ascending order from (0,0): position i is the sum of the last i moves of the walk, a prefix sum over the reversed move
-// list -- 64 positions per step, one coalesced 512-byte store each.
+// list -- 256 positions per trip: four independent move fetches first, then four 64-lane prefix sums and four 512-byte
+// stores whose lane 0 sits on a 128-byte line of the output (round 2: one fetch, one store per trip, each trip a full
+// memory latency: 3.4 TB/s of stores).
 constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
+constexpr int kWinRounds = 16;                           // rounds per walk window: one 128-byte line of code records
+constexpr int kWinQuads = kWinRounds / 2;                // uint4 = two rounds
 
 __global__ void __launch_bounds__(64)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
                     int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
 {
-    __shared__ uint4 line_codes[64][4 + 1];               // [lane][16-byte quarter of the line], padded
+    __shared__ uint4 line_codes[64][kWinQuads + 1];       // [lane][two rounds], padded
     const int lane = threadIdx.x;
     const uint32_t a0 = blockIdx.x * 64 + threadIdx.x;
     const bool real = a0 < n;
@@ -633,7 +640,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
-    int wmax = sum.y >> 3;
+    int wmax = sum.y / kWinRounds;
     wmax = row16_max(wmax);
     wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
                max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
@@ -641,31 +648,37 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     bool walking = (y | x) != 0;
     uint32_t steps = 0;
     unsigned acc_lo = 0, acc_hi = 0;                      // the last (steps & 31) moves, 2 bits each
+    auto load_window = [&](int w, uint4 (&buf)[kWinQuads]) {
+        const int wc = w > 0 ? w : 0;                     // below window 0: window 0 again (no branch around the loads)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) line_codes[lane][q] = my_codes[4 * wmax + q];
+        for (int q = 0; q < kWinQuads; ++q) buf[q] = my_codes[kWinQuads * wc + q];
+    };
+    auto to_lds = [&](const uint4 (&buf)[kWinQuads]) {    // each lane writes and reads its own row only: no barrier
+#pragma unroll
+        for (int q = 0; q < kWinQuads; ++q) line_codes[lane][q] = buf[q];
+    };
+    uint4 buf_a[kWinQuads], buf_b[kWinQuads], buf_c[kWinQuads];
+    load_window(wmax, buf_a);
+    load_window(wmax - 1, buf_b);
+    load_window(wmax - 2, buf_c);
     // Band row of a round r = r - (right moves up to and including r) = r - (rights_before + popcount of the block's move
     // bits up to r): no state carried from step to step, and a shorter dependency chain than an LDS lookup.
     // d_blk = move bits of the 32-round block the current window lies in; rights_before = right moves before that block,
     // known from the best round's band row when the wavefront reaches the block this walk starts in.
-    int blk = wmax >> 2;
+    int blk = wmax / 2;                                   // two windows per block of 32 rounds
     const int start_blk = sum.y >> 5;
     unsigned d_blk = my_dirs[(size_t)blk * n];
+    unsigned d_below = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;         // the block below, requested a block ahead
     int rights_before = 0;
     auto enter_block = [&]() {
         if (blk == start_blk) rights_before = (sum.y - sum.w) - __popc(d_blk & ((2u << (sum.y & 31)) - 1u));
     };
     enter_block();
-    for (int w = wmax; w >= 0; --w) {
-        // request the line of window w - 1 now; it is needed only after window w has been walked
-        // (window 0 re-requests itself: no branch around the loads, the values stay in registers)
-        const int wp = w > 0 ? w - 1 : 0;
-        const bool blk_changes = (w & 3) == 0 && w > 0;   // window w - 1 lies in the 32-round block below
-        const uint4 nc0 = my_codes[4 * wp], nc1 = my_codes[4 * wp + 1], nc2 = my_codes[4 * wp + 2], nc3 = my_codes[4 * wp + 3];
-        unsigned nd = 0;
-        if (blk_changes) nd = my_dirs[(size_t)(blk - 1) * n];
-        while (walking && ((y + x) >> 3) == w) {
+    to_lds(buf_a);
+    auto walk_window = [&](int w) {
+        while (walking && ((y + x) / kWinRounds) == w) {
             const int r = y + x;
-            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & 7];
+            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & (kWinRounds - 1)];
             const int top = r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
             const int bl = 31 - (y - top);
             const unsigned code = decode_code(cw, bl, tag_format);                   // never 0 on a live path
@@ -680,13 +693,22 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
             }
             walking = code != 0 && (y | x) != 0;
         }
-        line_codes[lane][0] = nc0; line_codes[lane][1] = nc1; line_codes[lane][2] = nc2; line_codes[lane][3] = nc3;
-        if (blk_changes) {
+    };
+    auto leave_window = [&](int w, const uint4 (&below)[kWinQuads]) {         // w > 0: window w - 1 comes next
+        to_lds(below);
+        if ((w & 1) == 0) {                               // window w - 1 lies in the 32-round block below
             --blk;
-            d_blk = nd;
+            d_blk = d_below;
+            d_below = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;
             rights_before -= (int)__popc(d_blk);
             enter_block();
         }
+    };
+    // roles at the top of the loop: LDS holds window w, buf_b window w - 1, buf_c window w - 2, buf_a is free
+    for (int w = wmax;;) {
+        load_window(w - 3, buf_a); walk_window(w); if (w == 0) break; leave_window(w, buf_b); --w;
+        load_window(w - 3, buf_b); walk_window(w); if (w == 0) break; leave_window(w, buf_c); --w;
+        load_window(w - 3, buf_c); walk_window(w); if (w == 0) break; leave_window(w, buf_a); --w;
     }
     if (real) {
         if (steps & 31u) my_moves[steps >> 5] = ((unsigned long long)acc_hi << 32) | acc_lo;
@@ -704,30 +726,41 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
     if (a >= n) return;
     const unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
-    const uint32_t total = lengths[a];                    // positions; moves 0 .. total-2 in walking order
-    const uint32_t limit = total < cap ? total : cap;     // positions to write
-    if (lane == 0 && limit > 0) out[0] = make_int2(0, 0);
-    unsigned carry = 0;                                   // y | x << 16 of position `base`
-    for (uint32_t base = 0; base + 1 < limit; base += 64) {
-        const uint32_t i = base + 1 + (uint32_t)lane;     // this lane's position, reached by move total - 1 - i
+    const int total = (int)lengths[a];                    // positions; moves 0 .. total-2 in walking order
+    const int limit = total < (int)cap ? total : (int)cap;                    // positions to write
+    // position i = the sum of the deltas of positions 1 .. i; the delta of position i is move total - 1 - i of the walk
+    auto delta = [&](int i) -> unsigned {
         unsigned d = 0;
-        if (i < total) {
-            const uint32_t t = total - 1 - i;
-            const unsigned code = (unsigned)(my_moves[t >> 5] >> (2 * (t & 31u))) & 3u;
+        if (i >= 1 && i < total) {
+            const int t = total - 1 - i;
+            const unsigned code = (unsigned)(my_moves[t >> 5] >> (2 * (t & 31))) & 3u;
             d = ((code == 1 || code == 2) ? 1u : 0u) | ((code == 1 || code == 3) ? 0x10000u : 0u);
         }
-        // inclusive prefix sum over the wavefront (y in the low half, x in the high half: both stay below 2^15)
-        unsigned v = d;
-        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-        const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
-                       r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-        const int row = lane >> 4;
-        v += carry + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
-        if (i < limit) out[i] = make_int2((int)(v & 0xFFFFu), (int)(v >> 16));
-        carry += r0 + r1 + r2 + r3;
+        return d;
+    };
+    // every 64-position store starts on a 128-byte line: the first chunk begins `skew` positions before out[0]
+    const int skew = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 15u);
+    unsigned carry = 0;                                   // y | x << 16 of the position before the chunk
+    for (int base = -skew; base < limit; base += 256) {
+        unsigned d[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = delta(base + 64 * c + lane);      // four independent fetches in flight
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = base + 64 * c + lane;
+            // inclusive prefix sum over the wavefront (y in the low half, x in the high half: both stay below 2^15)
+            unsigned v = d[c];
+            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
+                           r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+            const int row = lane >> 4;
+            v += carry + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+            if (i >= 0 && i < limit) out[i] = make_int2((int)(v & 0xFFFFu), (int)(v >> 16));
+            carry += r0 + r1 + r2 + r3;
+        }
     }
 }
 
@@ -754,12 +787,11 @@ namespace {
 // SWMI_SG_SWEEP forces one: 0, G or 10 * G + W.  The split kernels are compiled once per scheduling target W
 // (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per SIMD, and the version whose W matches what
 // the batch actually puts on a SIMD wins by 20-30 % (profiles/r01_sg_kernel_matrix.txt).
-int choose_sweep(size_t n, int compute_units)
+int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
 {
-    const char *force = getenv("SWMI_SG_SWEEP");
     int sweep = 0;
-    if (force) {
-        sweep = atoi(force);
+    if (tuning.force_sweep >= 0) {
+        sweep = tuning.force_sweep;
         if (sweep == 4) sweep = 44;
         if (sweep == 2) sweep = 24;
     } else if (n >= kSplit4MinBatch) {
@@ -777,27 +809,27 @@ int choose_sweep(size_t n, int compute_units)
     }
     return sweep;
 }
-bool choose_lane_traceback(size_t n)
+bool choose_lane_traceback(size_t n, const SgTuning &tuning)
 {
-    const char *force_tb = getenv("SWMI_SG_TRACEBACK");
-    return force_tb ? atoi(force_tb) == 1 : n >= kLaneTracebackMinBatch;
+    return tuning.force_traceback >= 0 ? tuning.force_traceback == 1 : n >= kLaneTracebackMinBatch;
 }
 }  // namespace
 
-void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len)
+void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len,
+                             SgTuning tuning)
 {
-    const int sweep = choose_sweep(n, compute_units);
+    const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep_name && sweep_len) {
         if (sweep != 0 && sweep < 100) snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep / 10, sweep % 10);
         else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
     }
     if (tb_name && tb_len)
-        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
+        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n, tuning) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
-                             hipEvent_t between, int compute_units)
+                             hipEvent_t between, int compute_units, SgTuning tuning)
 {
     if (n == 0) return hipSuccess;
     char *ws = static_cast<char *>(d_workspace);
@@ -808,7 +840,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     unsigned long long *moves = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
-    const int sweep = choose_sweep(n, compute_units);
+    const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep != 0 && sweep < 100) {
         const uint32_t per_block = sweep / 10 == 4 ? 16 : 32;               // alignments per sweep wavefront: 64 / G
         const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
@@ -841,7 +873,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
-    const bool lane_tb = choose_lane_traceback(n);
+    const bool lane_tb = choose_lane_traceback(n, tuning);
     if (lane_tb) {
         hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
                            summary, moves, d_scores, d_lengths);

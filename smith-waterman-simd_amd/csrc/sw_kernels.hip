@@ -353,12 +353,68 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 //   * per row and alignment pair: v_perm_b32, v_add_u32, v_pk_maximum3_f16, v_pk_sub_u16 clamp, (v_add_u32,) and half a
 //     v_pk_maximum3_f16 for the running best: 16 (Q = 0) / 18 nominal issue cycles per 2 cells;
 //   * issued in a hand-chosen order (pk_two_rows below).
+// Round 3: on this VALU every instruction of the cell costs one ~4.3-cycle issue slot whatever its class
+// (profiles/r03_microbench_cell_v3.txt), so what counts is the NUMBER of instructions, and two cell bodies with fewer of them
+// take over wherever the parameters allow (generated code, gen_pk_sweeps.py has the derivations):
+//   kPkQ0    every s + gap >= 0 (no bias needed): the diagonal adds of rows r, r + 1 are ONE v_lshl_add_u64 on an aligned
+//            register pair -- 8 instructions per two rows (round 2: 9);
+//   kPkVert  every s + 2 gap >= 0, e.g. (10,-30,15): row r works in its own domain D_r = gap (r + 1), which makes `up` the
+//            row above's max3 result as it is (chain max3 -> max3), takes the saturating subtraction and the re-biasing add
+//            off the chain and lets both adds pair -- 9 instructions per two rows (the bias form below: 11);
+//   kPkBias  everything else: the form described above.
 // Same anti-diagonal pipeline, DPP hand-over and pad-column argument as sw128_kernel (header of this file).
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+// The integers below 1024 are half-precision DENORMALS as bit patterns: make sure the wavefront keeps them (MODE.FP_DENORM
+// bits 7:6 = f16 / f64 input and output denormals allowed -- hipcc's default, set here so that no compile flag can undo it).
+// Every kernel that uses v_pk_maximum3_f16 as an integer max calls this first, pk_max3_selftest_kernel included.
+__device__ __forceinline__ void keep_f16_denormals()
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
+}
+
+// Self-test of the premise above (swmi_selftest_pk_max3; tests/test_gpu_pk_kernels.py runs it under pytest -m gpu): for
+// EVERY pair (a, b) of 16-bit integers in [0, 0x7C00) -- 31744^2 = 1.0e9 pairs -- the packed max3 of registers built from
+// a, b and a pseudo-random third value r equals the integer max3 of each half, with the third operand one of the two, the
+// random one, and in every operand position.  Thread = one a, kBPerThread consecutive b.
+constexpr uint32_t kPkLimit = 0x7C00u;      // first f16 bit pattern that is not a finite number (+Inf)
+constexpr uint32_t kBPerThread = 1024;
+__global__ void __launch_bounds__(256)
+pk_max3_selftest_kernel(unsigned long long *__restrict__ counts /* [0] checked, [1] mismatches */)
+{
+    keep_f16_denormals();
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b0 = blockIdx.y * kBPerThread;
+    if (a >= kPkLimit) return;
+    auto imax3 = [](uint32_t p, uint32_t q, uint32_t r) { const uint32_t m = p > q ? p : q; return m > r ? m : r; };
+    // (the instruction as the scoring kernel issues it, followed by the wait states pk_two_rows keeps between a packed result
+    // and its consumer -- here the consumer is whatever hipcc schedules next)
+    auto pk_max3 = [](uint32_t p, uint32_t q, uint32_t r) {
+        uint32_t o;
+        asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(q), "v"(r));
+        return o;
+    };
+    uint32_t bad = 0, done = 0;
+    for (uint32_t b = b0; b < b0 + kBPerThread && b < kPkLimit; ++b) {
+        uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u);
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        const uint32_t r = h % kPkLimit, r2 = (h >> 7) % kPkLimit;
+        const uint32_t x = a | (b << 16), y = b | (r << 16), z = r2 | (a << 16);
+        // each line: the packed result against the integer max3 of the low halves | the high halves
+        bad += pk_max3(x, y, z) != (imax3(a, b, r2) | (imax3(b, r, a) << 16));
+        bad += pk_max3(z, x, y) != (imax3(r2, a, b) | (imax3(a, b, r) << 16));
+        bad += pk_max3(y, z, x) != (imax3(b, r2, a) | (imax3(r, a, b) << 16));
+        bad += pk_max3(x, y, x) != (imax3(a, b, a) | (imax3(b, r, b) << 16));      // third operand = one of the two
+        bad += pk_max3(x, y, y) != (imax3(a, b, b) | (imax3(b, r, r) << 16));
+        bad += pk_max3(x, x, y) != (imax3(a, a, b) | (imax3(b, b, r) << 16));
+        done += 6;
+    }
+    atomicAdd(&counts[0], (unsigned long long)done);
+    if (bad) atomicAdd(&counts[1], (unsigned long long)bad);
 }
 // TWO ROWS of the packed cell as one block of assembly, in a hand-chosen order of issue:
 //   * a wavefront issues in order and a dependent instruction waits for its producer, so an independent instruction sits
@@ -374,13 +430,13 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
 // Rows i (suffix 0) and i+1 (suffix 1).  in: t = diagonal term of row i, sc = looked-up scores of row i+1, up = H + Q of
 // the row above;  out: t = diagonal term of row i+2, sc = scores of row i+3; hq1 is the next block's `up`.
 // LAST: rows R-2, R-1 -- nothing to look ahead to; s_nop keeps the spacing.
-template <bool BIAS, bool LAST>
+template <bool LAST>
 __device__ __forceinline__ void pk_two_rows(uint32_t &hq0, uint32_t &hq1, uint32_t &hu0, uint32_t &hu1, uint32_t &best, uint32_t &t,
                                             uint32_t &sc, uint32_t up, uint32_t sel2, uint32_t sel3, uint32_t cx, uint32_t cy,
                                             uint32_t gq2, uint32_t q2)
 {
     uint32_t x0, x1, s2;
-    if constexpr (BIAS && !LAST) {
+    if constexpr (!LAST) {
         asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"          // M0   x + Q
                      "v_add_u32 %[t], %[hu0], %[sc]\n\t"                          // T1   H(row i, previous column) + score
                      "s_nop 0\n\t"
@@ -399,7 +455,7 @@ __device__ __forceinline__ void pk_two_rows(uint32_t &hq0, uint32_t &hq1, uint32
                      : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [hu0] "+v"(hu0), [hu1] "+v"(hu1), [best] "+v"(best), [t] "+v"(t),
                        [sc] "+v"(sc), [x0] "=&v"(x0), [x1] "=&v"(x1), [s2] "=&v"(s2)
                      : [up] "v"(up), [sel2] "v"(sel2), [sel3] "v"(sel3), [cx] "v"(cx), [cy] "v"(cy), [gq] "s"(gq2), [q] "s"(q2));
-    } else if constexpr (BIAS && LAST) {
+    } else {
         asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"
                      "v_add_u32 %[t], %[hu0], %[sc]\n\t"
                      "s_nop 0\n\t"
@@ -415,45 +471,26 @@ __device__ __forceinline__ void pk_two_rows(uint32_t &hq0, uint32_t &hq1, uint32
                      : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [hu0] "+v"(hu0), [hu1] "+v"(hu1), [best] "+v"(best), [t] "+v"(t),
                        [x0] "=&v"(x0), [x1] "=&v"(x1)
                      : [up] "v"(up), [sc] "v"(sc), [gq] "s"(gq2), [q] "s"(q2));
-    } else if constexpr (!LAST) {
-        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"          // M0    (k = 0)
-                     "v_add_u32 %[t], %[hq0], %[sc]\n\t"                          // T1    reads H of row i BEFORE S0 replaces it
-                     "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[hq0], %[x0], %[gq] clamp\n\t"                // S0
-                     "v_perm_b32 %[s2], %[cy], %[cx], %[sel2]\n\t"                // P2
-                     "s_nop 0\n\t"
-                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"          // M1
-                     "v_add_u32 %[t], %[hq1], %[s2]\n\t"                          // T2
-                     "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[hq1], %[x1], %[gq] clamp\n\t"                // S1
-                     "v_perm_b32 %[sc], %[cy], %[cx], %[sel3]\n\t"                // P3
-                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]"           // B
-                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [best] "+v"(best), [t] "+v"(t), [sc] "+v"(sc), [x0] "=&v"(x0),
-                       [x1] "=&v"(x1), [s2] "=&v"(s2)
-                     : [up] "v"(up), [sel2] "v"(sel2), [sel3] "v"(sel3), [cx] "v"(cx), [cy] "v"(cy), [gq] "s"(gq2));
-    } else {
-        asm volatile("v_pk_maximum3_f16 %[x0], %[hq0], %[up], %[t]\n\t"
-                     "v_add_u32 %[t], %[hq0], %[sc]\n\t"
-                     "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[hq0], %[x0], %[gq] clamp\n\t"
-                     "s_nop 0\n\t"
-                     "v_pk_maximum3_f16 %[x1], %[hq1], %[hq0], %[t]\n\t"
-                     "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[hq1], %[x1], %[gq] clamp\n\t"
-                     "v_pk_maximum3_f16 %[best], %[best], %[x0], %[x1]"
-                     : [hq0] "+v"(hq0), [hq1] "+v"(hq1), [best] "+v"(best), [t] "+v"(t), [x0] "=&v"(x0), [x1] "=&v"(x1)
-                     : [up] "v"(up), [sc] "v"(sc), [gq] "s"(gq2));
     }
 }
 
 // L = 4 (32 rows per lane, 32 alignments per wavefront) is what large batches run; L = 8 and 16 are the same kernel with
 // 16 / 8 rows per lane and 16 / 8 alignments per wavefront, for launches that do not fill the chip at L = 4.
-template <int MODE, bool BIAS, int L>
+// VARIANT: the cell body (the host picks it from the parameters, swmi_api.cpp make_config)
+//   kPkQ0    every s + gap >= 0: no bias; the two diagonal adds of a row pair are ONE v_lshl_add_u64 (generated sweep)
+//   kPkBias  any parameters: values shifted by Q (round 2's form, pk_two_rows above)
+//   kPkVert  every s + 2 gap >= 0 (and the row offsets fit): vertical-offset form (generated sweep, gen_pk_sweeps.py)
+// (round 2's unbiased form, pk_two_rows<false>, ran 2-3 % slower than kPkQ0 and is gone: profiles/r03_pk_variants_timing.txt)
+enum PkVariant : int { kPkQ0 = 0, kPkBias = 1, kPkVert = 2 };
+
+template <int MODE, int VARIANT, int L>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4)))
 sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
-                uint32_t n, SmRows rows /* s + gap + Q, every byte in [0, 255] */, int gap, int q)
+                uint32_t n, SmRows rows /* s + gap + Q (kPkVert: s + 2 gap), every byte in [0, 255] */, int gap, int q)
 {
     static_assert(L == 4 || L == 8 || L == 16, "lanes per pair of alignments");
+    constexpr bool BIAS = VARIANT == kPkBias;
+    constexpr bool kGenerated = VARIANT == kPkQ0 || VARIANT == kPkVert;
     constexpr int R = kSeqLen / L;          // rows per lane (L = lanes per pair of alignments)
     constexpr int G = 64 / L;               // lane groups per wavefront, each walking TWO alignments
     constexpr int A = 2 * G;                // alignments per wavefront
@@ -524,9 +561,7 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_s_setprio(2);
 
-    // The integers below 1024 are half-precision DENORMALS as bit patterns: make sure the wavefront keeps them (MODE.FP_DENORM
-    // bits 7:6 = f16 / f64 input and output denormals allowed -- hipcc's default, set here so that no compile flag can undo it).
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
+    keep_f16_denormals();
 
     // Two copies of the previous column, X in the low half and Y in the high half of every register:
     //   hq[i] = H(row i) + Q   what `left` and `up` are (the max3 runs on values shifted by Q, which keeps the diagonal term
@@ -536,41 +571,67 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     // into the high one.  With Q = 0 (BIAS = false) the two copies are one.
     const uint32_t gq2 = (uint32_t)(gap + q) | ((uint32_t)(gap + q) << 16);
     const uint32_t q2 = (uint32_t)q | ((uint32_t)q << 16);
-    uint32_t hq[R], hu_[R];                 // (hu_ is dead code when Q = 0)
-#pragma unroll
-    for (int i = 0; i < R; ++i) { hq[i] = q2; hu_[i] = 0; }
-    uint32_t best = 0, u0 = q2, u1 = q2;
+    uint32_t best = 0;
     const int group_mask = keep(j == 0 ? 0 : -1);
-    const uint32_t edge = (uint32_t)keep((int)(j == 0 ? q2 : 0u));   // above the first row of an alignment: H = 0
     const uint32_t *col = prof + PAD - j;   // col[t] = table offsets of column t - j
-
-    auto step = [&](uint32_t cx, uint32_t cy, uint32_t up, uint32_t diag) {
-        uint32_t d0 = diag;
-        if constexpr (BIAS) d0 = diag - q2;                                     // H of the diagonal neighbour of row 0
-        uint32_t t = d0 + __builtin_amdgcn_perm(cy, cx, rsel[0]);               // diagonal term of row 0
-        uint32_t sc = __builtin_amdgcn_perm(cy, cx, rsel[1]);                   // scores of row 1
-#pragma unroll
-        for (int i = 0; i < R; i += 2) {
-            if constexpr (BIAS) {
-                if (i + 2 < R) pk_two_rows<true, false>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, rsel[i + 2], rsel[i + 3], cx, cy, gq2, q2);
-                else           pk_two_rows<true, true>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, 0, 0, cx, cy, gq2, q2);
-            } else {
-                uint32_t none0 = 0, none1 = 0;      // Q = 0: H + Q and H are the same registers
-                if (i + 2 < R) pk_two_rows<false, false>(hq[i], hq[i + 1], none0, none1, best, t, sc, up, rsel[i + 2], rsel[i + 3], cx, cy, gq2, q2);
-                else           pk_two_rows<false, true>(hq[i], hq[i + 1], none0, none1, best, t, sc, up, 0, 0, cx, cy, gq2, q2);
-            }
-            up = hq[i + 1];
-        }
-        asm volatile("s_nop 1");            // the DPP below reads a register the asm above wrote: 2 wait states, by hand
-        uint32_t out = (uint32_t)from_prev_lane<L>((int)hq[R - 1], group_mask);
-        if constexpr (BIAS) out |= edge;
-        return out;
-    };
     auto tables = [&](uint32_t code, uint32_t &cx, uint32_t &cy) {
         cx = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code & 0xFFFFu));
         cy = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code >> 16));
     };
 
+    if constexpr (kGenerated) {
+        // The sweep as generated code (gen_pk_sweeps.py -> pk_sweeps_gen.inc): the column in explicit register variables so
+        // that two rows share a 64-bit add; one asm statement per instruction, issued in the order written.
+#define pk_best best
+#define pk_dval(r) ((uint32_t)(gap * ((r) + 1)) * 0x10001u)      /* D_r = gap (r + 1) in both halves (kPkVert) */
+        if constexpr (VARIANT == kPkQ0 && R == 32) {
+#define PK_SECTION 32
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        } else if constexpr (VARIANT == kPkQ0 && R == 16) {
+#define PK_SECTION 16
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        } else if constexpr (VARIANT == kPkQ0 && R == 8) {
+#define PK_SECTION 8
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        } else if constexpr (VARIANT == kPkVert && R == 32) {
+#define PK_SECTION 232
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        } else if constexpr (VARIANT == kPkVert && R == 16) {
+#define PK_SECTION 216
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        } else {
+#define PK_SECTION 208
+#include "pk_sweeps_gen.inc"
+#undef PK_SECTION
+        }
+#undef pk_best
+#undef pk_dval
+    } else {
+    uint32_t hq[R], hu_[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { hq[i] = q2; hu_[i] = 0; }
+    uint32_t u0 = q2, u1 = q2;
+    const uint32_t edge = (uint32_t)keep((int)(j == 0 ? q2 : 0u));   // above the first row of an alignment: H = 0
+
+    auto step = [&](uint32_t cx, uint32_t cy, uint32_t up, uint32_t diag) {
+        const uint32_t d0 = diag - q2;                                          // H of the diagonal neighbour of row 0
+        uint32_t t = d0 + __builtin_amdgcn_perm(cy, cx, rsel[0]);               // diagonal term of row 0
+        uint32_t sc = __builtin_amdgcn_perm(cy, cx, rsel[1]);                   // scores of row 1
+#pragma unroll
+        for (int i = 0; i < R; i += 2) {
+            if (i + 2 < R) pk_two_rows<false>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, rsel[i + 2], rsel[i + 3], cx, cy, gq2, q2);
+            else           pk_two_rows<true>(hq[i], hq[i + 1], hu_[i], hu_[i + 1], best, t, sc, up, 0, 0, cx, cy, gq2, q2);
+            up = hq[i + 1];
+        }
+        asm volatile("s_nop 1");            // the DPP below reads a register the asm above wrote: 2 wait states, by hand
+        uint32_t out = (uint32_t)from_prev_lane<L>((int)hq[R - 1], group_mask);
+        return out | edge;
+    };
     uint32_t c1 = col[1], x0, y0;
     tables(col[0], x0, y0);
     for (int t2 = 0; t2 < T2; ++t2) {
@@ -583,14 +644,15 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
         x0 = x2; y0 = y2; c1 = c3;
     }
     step(x0, y0, u0, u1);                   // step 128 + L - 2, the last lane's last column
+    }
 
-    // reduce over the L lanes of the group (packed), then unfold: the maximum was tracked on x + Q = H + gap + Q
+    // reduce over the L lanes of the group (packed), then unfold: the maximum was tracked on x + Q = H + gap + Q (kPkVert: on H)
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
         best = pk_max3(best, other, other);
     }
-    const int bx_score = (int)(best & 0xFFFFu), by_score = (int)(best >> 16), gq = gap + q;
+    const int bx_score = (int)(best & 0xFFFFu), by_score = (int)(best >> 16), gq = VARIANT == kPkVert ? 0 : gap + q;
     if (j == 0) {
         if (live_x) scores[px] = bx_score > gq ? bx_score - gq : 0;
         if (live_y) scores[py] = by_score > gq ? by_score - gq : 0;
@@ -1011,8 +1073,11 @@ hipError_t launch_L(const LaunchConfig &cfg, const uint8_t *s1, const uint8_t *s
         if (cfg.use_pk) {                   // two alignments per register (rows = s + gap + pk_bias, one byte each)
             const size_t waves_pk = (n + 2 * A - 1) / (2 * A);
             const dim3 grid_pk((unsigned)((waves_pk + kWavesPerBlock - 1) / kWavesPerBlock));
-            if (cfg.pk_bias) hipLaunchKernelGGL((sw128_pk_kernel<MODE, true, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, cfg.pk_bias);
-            else             hipLaunchKernelGGL((sw128_pk_kernel<MODE, false, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0);
+            switch (cfg.pk_variant) {
+            case kPkQ0:    hipLaunchKernelGGL((sw128_pk_kernel<MODE, kPkQ0, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0); break;
+            case kPkVert:  hipLaunchKernelGGL((sw128_pk_kernel<MODE, kPkVert, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, 0); break;
+            default:       hipLaunchKernelGGL((sw128_pk_kernel<MODE, kPkBias, L>), grid_pk, block, cfg.extra_lds_bytes, stream, s1, s2, out, n32, rows, gap, cfg.pk_bias); break;
+            }
             return hipGetLastError();
         }
     }
@@ -1069,7 +1134,7 @@ hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_se
 }
 
 hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
-                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream)
+                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream, bool allow_i16)
 {
     if (n == 0) return hipSuccess;
     const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1082,7 +1147,7 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
             const int v = (int)(int8_t)(rows.r[a] >> (8 * b));
             top = v > top ? v : top;
         }
-    const bool i16 = (long long)len * top < 32768 && !getenv("SWMI_BANDED_NO_I16");
+    const bool i16 = (long long)len * top < 32768 && allow_i16;
     const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
     if (gap_open >= gap_ext) {
         if (i16) hipLaunchKernelGGL((sw_banded_affine_kernel<true, true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
@@ -1090,6 +1155,13 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
     } else {
         hipLaunchKernelGGL((sw_banded_affine_kernel<false, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pk_max3_selftest(unsigned long long *d_counts, hipStream_t stream)
+{
+    const dim3 grid((kPkLimit + 255) / 256, (kPkLimit + kBPerThread - 1) / kBPerThread);
+    hipLaunchKernelGGL(pk_max3_selftest_kernel, grid, dim3(256), 0, stream, d_counts);
     return hipGetLastError();
 }
 

@@ -19,8 +19,10 @@ namespace {
 thread_local char t_error[512] = "";
 thread_local int t_status = SWMI_OK;               // code of the last fail() on this thread
 thread_local int t_gpu = 0;                        // context index this thread addresses (swmi_use_gpu)
-std::vector<std::unique_ptr<Context>> g_ctxs;      // written only under g_init_mu, by swmi_init* / swmi_shutdown
+std::vector<std::shared_ptr<Context>> g_ctxs;      // written only under g_init_mu, by swmi_init* / swmi_shutdown
 std::mutex g_init_mu;
+Knobs g_knobs;                                     // written only under g_init_mu (read_knobs)
+bool g_knobs_read = false;
 // Schedule setting, process-wide: lanes in the low half, flags in the high half, ONE atomic so that a launch that races
 // with swmi_set_schedule sees either the old pair or the new one, never a mix.
 std::atomic<uint64_t> g_schedule{0};
@@ -41,6 +43,39 @@ int last_status() { return t_status; }
 std::mutex &init_mutex() { return g_init_mu; }
 int num_contexts() { return (int)g_ctxs.size(); }
 Context *context_at(int index) { return index >= 0 && index < (int)g_ctxs.size() ? g_ctxs[index].get() : nullptr; }
+std::shared_ptr<Context> context_ref(int index) { return index >= 0 && index < (int)g_ctxs.size() ? g_ctxs[index] : nullptr; }
+
+int check_alive(const Context &ctx)
+{
+    if (!ctx.dead.load(std::memory_order_acquire)) return SWMI_OK;
+    return fail(SWMI_ERR_NOT_INITIALIZED, "swmi_shutdown() ran after this handle was created: only its *_destroy call is valid now");
+}
+
+const Knobs &knobs() { return g_knobs; }
+
+void read_knobs()
+{
+    Knobs k;
+    auto num = [](const char *name, long long lo, long long hi, long long dflt) {
+        const char *v = getenv(name);
+        if (!v || !*v) return dflt;
+        const long long x = atoll(v);
+        return x < lo || x > hi ? dflt : x;
+    };
+    k.host_granule = (size_t)num("SWMI_HOST_GRANULE", 1024, (long long)kChunkPairs, 0);
+    k.host_serial = num("SWMI_HOST_SERIAL", 0, 1, 0) != 0;
+    k.extra_lds = (unsigned)num("SWMI_EXTRA_LDS", 0, 160 * 1024, 0);
+    k.lanes = (int)num("SWMI_LANES", 0, 64, 0);
+    k.banded_no_i16 = getenv("SWMI_BANDED_NO_I16") != nullptr;
+    k.sg_sweep = (int)num("SWMI_SG_SWEEP", 0, 199, -1);
+    k.sg_traceback = (int)num("SWMI_SG_TRACEBACK", 0, 1, -1);
+    const char *gb = getenv("SWMI_GATHER_BACKEND");
+    k.gather_p2p = gb && strcmp(gb, "p2p") == 0;
+    k.gather_piece = (size_t)num("SWMI_TEST_GATHER_PIECE", 1, 1ll << 40, 0);
+    if (const char *lib = getenv("SWMI_RCCL_LIB")) snprintf(k.rccl_lib, sizeof k.rccl_lib, "%s", lib);
+    g_knobs = k;
+    g_knobs_read = true;
+}
 
 Context *current()
 {
@@ -108,6 +143,8 @@ LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *
     cfg.use_i16 = (flags & swmi::kUseI16) != 0;
     cfg.use_lut = (flags & swmi::kUseLut) != 0;
     cfg.extra_lds_bytes = ctx.extra_lds;
+    cfg.pk_bias = 0;
+    cfg.pk_variant = 0;
     bool fold = !(flags & swmi::kNoGapFold);
     for (int k = 0; k < 16 && fold; ++k) {
         const int v = int(sm[k]) + gap;
@@ -120,13 +157,33 @@ LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *
     cfg.use_pk = (cfg.lanes_per_alignment == 4 || cfg.lanes_per_alignment == 8 || cfg.lanes_per_alignment == 16) &&
                  !(flags & (swmi::kNoPacked | swmi::kNoGapFold | swmi::kUseI16 | swmi::kUseLut));
     cfg.pk_bias = 0;
+    cfg.pk_variant = 0;
     if (cfg.use_pk) {
-        int lowest = 255;
-        for (int k = 0; k < 16; ++k) lowest = int(sm[k]) + gap < lowest ? int(sm[k]) + gap : lowest;
-        cfg.pk_bias = lowest < 0 ? -lowest : 0;
+        int lowest = 255, highest = -255;
+        for (int k = 0; k < 16; ++k) {
+            lowest = int(sm[k]) < lowest ? int(sm[k]) : lowest;
+            highest = int(sm[k]) > highest ? int(sm[k]) : highest;
+        }
+        // Which cell body (sw_kernels.hip PkVariant; tests/test_gpu_pk_kernels.py restates the rule):
+        //   0  every s + gap >= 0: nothing to bias
+        //   2  every s + 2 gap in [0, 255] and the largest value of the vertical-offset form, 128 max(s) + gap * 34 + 255,
+        //      stays a finite half-precision pattern (< 0x7C00): rows carry s + 2 gap
+        //   1  anything else: values shifted by Q = -(min s + gap)
+        int add = gap;
+        if (lowest + gap >= 0) {
+            cfg.pk_variant = 0;
+        } else if (lowest + 2 * gap >= 0 && highest + 2 * gap <= 255 &&
+                   128 * (highest > 0 ? highest : 0) + 34 * gap + 256 < 0x7C00) {
+            cfg.pk_variant = 2;
+            add = 2 * gap;
+        } else {
+            cfg.pk_variant = 1;
+            cfg.pk_bias = -(lowest + gap);
+            add = gap + cfg.pk_bias;
+        }
         for (int a = 0; a < 4; ++a) {
             uint32_t r = 0;
-            for (int b = 0; b < 4; ++b) r |= uint32_t(int(sm[4 * a + b]) + gap + cfg.pk_bias) << (8 * b);
+            for (int b = 0; b < 4; ++b) r |= uint32_t(int(sm[4 * a + b]) + add) << (8 * b);
             rows->r[a] = r;
         }
         return cfg;
@@ -167,43 +224,105 @@ int launch_device(Context &ctx, const void *d1, const void *d2, size_t n, const 
     return SWMI_OK;
 }
 
-// Host-resident batch: two slots, each with its own stream; chunk k+1's H2D copy overlaps chunk k's kernel.
+// Pipeline granules of a host batch.  The link, not the kernel, bounds this path (256 B per pair over PCIe against
+// ~1.1 ns of kernel time per pair), so the schedule is built to keep the link busy and to leave as little as possible
+// behind the last copy: granules TAPER -- each is three quarters of what is left, at most kChunkPairs, and whatever is left
+// below kMinGranule goes as one -- so the kernel that runs exposed at the very end covers 16 K pairs (~30 us), while the
+// number of copy commands stays small (a 1M-pair batch: 768 K, 192 K, 48 K, 16 K).  A kernel is ~4x faster than the copy of
+// its own granule, so granule k's kernel is always done before granule k + 1's (smaller) copy is.
+size_t next_granule(size_t remaining)
+{
+    const size_t fixed = knobs().host_granule;
+    if (fixed) return remaining < fixed ? remaining : fixed;
+    if (remaining <= kMinGranule) return remaining;
+    size_t g = (remaining - remaining / 4) & ~size_t(4095);
+    if (g > kChunkPairs) g = kChunkPairs;
+    if (g < kMinGranule) g = kMinGranule;
+    return g;
+}
+
+namespace {
+int ensure_scores_all(Context &ctx, size_t pairs)
+{
+    if (ctx.scores_all_capacity >= pairs) return SWMI_OK;
+    if (ctx.d_scores_all) { (void)hipFree(ctx.d_scores_all); ctx.d_scores_all = nullptr; }
+    ctx.scores_all_capacity = 0;
+    SWMI_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_scores_all), pairs * sizeof(int32_t)));
+    ctx.scores_all_capacity = pairs;
+    return SWMI_OK;
+}
+}  // namespace
+
+// Host-resident batch (the body of swmi_score_batch and its relatives).  kSlots input buffer sets, a stream each;
+// granule k: H2D of its two arrays, then its kernel, on stream k % kSlots, writing into ONE device score vector for the
+// whole group of granules.  Nothing is copied back until every granule of the group has been issued: a copy into pageable
+// memory blocks the calling thread until the stream reaches it, and round 2's pipeline -- D2H behind every granule --
+// therefore never had granule k + 1's H2D in flight while granule k's kernel ran (profiles/r02_host_staging_experiment.txt:
+// 4 x (4.9 + 1.5) ms for 4M pairs).  Now the host is only ever blocked inside an H2D copy (pageable memory) or not at all
+// (pinned), granule k's kernel runs under granule k + 1's copy, and one D2H per group (up to kScoreGroup pairs, 64 MiB of
+// scores) follows the group's last kernel.
 int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
                      bool packed, bool one_vs_many)
 {
     std::lock_guard<std::mutex> lock(ctx.mu);
     const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
-    size_t chunk_cap = kChunkPairs;
-    if (const char *env = getenv("SWMI_HOST_CHUNK")) {     // experiment knob: pairs per pipeline granule
-        const long long v = atoll(env);
-        if (v >= 1024 && size_t(v) <= kChunkPairs) chunk_cap = size_t(v);
+    const bool serial = knobs().host_serial;             // round 2's order of issue, for the A/B
+    const size_t largest = next_granule(n);
+    int used_slots = 0;
+    {
+        size_t rem = n;
+        while (rem && used_slots < kSlots) { rem -= next_granule(rem); ++used_slots; }
     }
-    const size_t chunk = n < chunk_cap ? n : chunk_cap;
-    SmRows rows;
-    const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, chunk);
-    for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
-        const int rc = ensure_slot(ctx.slots[k], chunk);
+    for (int k = 0; k < used_slots; ++k) {
+        const int rc = ensure_slot(ctx.slots[k], largest);
+        if (rc != SWMI_OK) return rc;
+    }
+    {
+        const int rc = ensure_scores_all(ctx, n < kScoreGroup ? n : kScoreGroup);
         if (rc != SWMI_OK) return rc;
     }
     hipError_t e = hipSuccess;
     if (one_vs_many)   // the single seq2 goes to the head of the seq2 buffer of every slot in use
-        for (int k = 0; k < kSlots && size_t(k) * chunk < n && e == hipSuccess; ++k)
+        for (int k = 0; k < used_slots && e == hipSuccess; ++k)
             e = hipMemcpyAsync(ctx.slots[k].d_seq2, s2, kSeq, hipMemcpyHostToDevice, ctx.slots[k].stream);
     size_t idx = 0;
-    for (size_t off = 0; off < n && e == hipSuccess; off += chunk, ++idx) {
-        Slot &s = ctx.slots[idx % kSlots];
-        const size_t m = n - off < chunk ? n - off : chunk;
-        e = hipMemcpyAsync(s.d_seq1, s1 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
-        if (e == hipSuccess && !one_vs_many)
-            e = hipMemcpyAsync(s.d_seq2, s2 + off * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+    for (size_t group = 0; group < n && e == hipSuccess; group += kScoreGroup) {
+        const size_t group_n = n - group < kScoreGroup ? n - group : kScoreGroup;
+        bool slot_used[kSlots] = {};
+        Slot *last_slot = nullptr;
+        for (size_t off = 0; off < group_n && e == hipSuccess; ++idx) {
+            const size_t m = next_granule(group_n - off), at = group + off;
+            const int which = int(idx % kSlots);
+            Slot &s = ctx.slots[which];
+            SmRows rows;
+            const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, m);      // a small tail granule runs more lanes per alignment
+            e = hipMemcpyAsync(s.d_seq1, s1 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+            if (e == hipSuccess && !one_vs_many)
+                e = hipMemcpyAsync(s.d_seq2, s2 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+            if (e == hipSuccess)
+                e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, s.stream)
+                                : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, packed, s.stream);
+            if (e == hipSuccess && serial)
+                e = hipMemcpyAsync(out + at, ctx.d_scores_all + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+            slot_used[which] = true;
+            last_slot = &s;
+            off += m;
+        }
+        if (e != hipSuccess || serial || !last_slot) continue;
+        // the group's scores: one copy on the last granule's stream, behind every other slot's last kernel
+        for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
+            if (!slot_used[k] || &ctx.slots[k] == last_slot) continue;
+            e = hipEventRecord(ctx.slot_done[k], ctx.slots[k].stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(last_slot->stream, ctx.slot_done[k], 0);
+        }
         if (e == hipSuccess)
-            e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, s.stream)
-                            : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, s.d_scores, m, rows, gap, packed, s.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out + off, s.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+            e = hipMemcpyAsync(out + group, ctx.d_scores_all, group_n * sizeof(int32_t), hipMemcpyDeviceToHost, last_slot->stream);
+        // the next group overwrites d_scores_all: drain this one first (only batches above kScoreGroup pairs get here twice)
+        if (e == hipSuccess && group + group_n < n) e = hipStreamSynchronize(last_slot->stream);
     }
     for (int k = 0; k < kSlots; ++k)
         if (ctx.slots[k].stream) {
-            const hipError_t es = hipStreamSynchronize(ctx.slots[k].stream);      // on failure too: see drain_slots
+            const hipError_t es = hipStreamSynchronize(ctx.slots[k].stream);      // on failure too: copies in flight use the caller's buffers
             if (e == hipSuccess) e = es;
         }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "host batch on GPU %d failed: %s", ctx.device, hipGetErrorString(e));
@@ -221,7 +340,8 @@ using swmi::SmRows;
 // ---- deferred queue ------------------------------------------------------------------------------
 
 struct swmi_queue {
-    Context *ctx = nullptr;             // the GPU the queue was created on
+    std::shared_ptr<Context> ctx;       // the GPU the queue was created on (kept alive past swmi_shutdown, see Context::dead)
+    int device = -1;                    // its HIP ordinal: all that swmi_queue_destroy needs
     size_t max_pairs = 0, count = 0, shipped = 0;
     size_t block = 1 << 16;             // pairs per asynchronous shipment
     int8_t sm[16];
@@ -237,7 +357,9 @@ namespace {
 int queue_ship(swmi_queue *q, size_t upto)
 {
     if (upto <= q->shipped) return SWMI_OK;
-    HIP_TRY(hipSetDevice(q->ctx->device));
+    const int alive = check_alive(*q->ctx);
+    if (alive != SWMI_OK) return alive;
+    HIP_TRY(hipSetDevice(q->device));
     const size_t off = q->shipped, m = upto - q->shipped;
     HIP_TRY(hipMemcpyAsync(q->d_seq1 + off * kSeq, q->h_seq1 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
     HIP_TRY(hipMemcpyAsync(q->d_seq2 + off * kSeq, q->h_seq2 + off * kSeq, m * kSeq, hipMemcpyHostToDevice, q->stream));
@@ -262,6 +384,13 @@ void destroy_context(Context &c)
     }
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c.stream = nullptr;
+    if (c.d_scores_all) (void)hipFree(c.d_scores_all);
+    c.d_scores_all = nullptr;
+    c.scores_all_capacity = 0;
+    for (auto &ev : c.slot_done) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
     for (auto &w : c.sg_workspaces)
         if (w.second.ptr) (void)hipFree(w.second.ptr);
     c.sg_workspaces.clear();
@@ -285,19 +414,20 @@ int create_context(Context &c, int index, int device)
                     c.prop.gcnArchName);
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     for (auto &s : c.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (auto &ev : c.slot_done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.pin), kPinPairs * (2 * kSeq + sizeof(int32_t)), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(&c.pin_dev, c.pin, 0));
-    const char *env_x = getenv("SWMI_EXTRA_LDS");
-    c.extra_lds = env_x ? (unsigned)atoi(env_x) : 0;
+    c.extra_lds = knobs().extra_lds;
     return SWMI_OK;
 }
 
 // Bind the listed devices (under g_init_mu).  All or nothing.
 int init_list(const int *devices, int n)
 {
-    std::vector<std::unique_ptr<Context>> fresh;
+    read_knobs();                       // the SWMI_* environment, once per initialisation
+    std::vector<std::shared_ptr<Context>> fresh;
     for (int k = 0; k < n; ++k) {
-        fresh.emplace_back(new Context);
+        fresh.emplace_back(std::make_shared<Context>());
         const int rc = create_context(*fresh.back(), k, devices[k]);
         if (rc != SWMI_OK) {
             for (auto &c : fresh) destroy_context(*c);
@@ -318,8 +448,7 @@ int init_list(const int *devices, int n)
             }
     (void)hipSetDevice(devices[0]);
     g_ctxs = std::move(fresh);
-    const char *env_l = getenv("SWMI_LANES");
-    if (env_l && swmi::schedule_supported(atoi(env_l))) g_schedule.store(uint64_t(atoi(env_l)));
+    if (knobs().lanes && swmi::schedule_supported(knobs().lanes)) g_schedule.store(uint64_t(knobs().lanes));
     return SWMI_OK;
 }
 
@@ -410,7 +539,10 @@ int swmi_use_gpu(int index)
 int swmi_shutdown(void)
 {
     std::lock_guard<std::mutex> lock(g_init_mu);
-    for (auto &c : g_ctxs) destroy_context(*c);
+    for (auto &c : g_ctxs) {
+        destroy_context(*c);
+        c->dead.store(true, std::memory_order_release);     // handles that outlive the shutdown find this, not freed memory
+    }
     g_ctxs.clear();
     t_gpu = 0;
     return SWMI_OK;
@@ -447,8 +579,8 @@ int swmi_score_kernel_for_batch(size_t n, const int8_t score_matrix[16], int8_t 
     const int L = cfg.lanes_per_alignment;
     int per_wave = 64 / L;
     if (cfg.use_pk) {
-        if (L == 4) snprintf(name, name_len, "sw128_pk_kernel<%d,%d>", mode, cfg.pk_bias ? 1 : 0);
-        else        snprintf(name, name_len, "sw128_pk_kernel<%d,%d,%d>", mode, cfg.pk_bias ? 1 : 0, L);
+        if (L == 4) snprintf(name, name_len, "sw128_pk_kernel<%d,%d>", mode, cfg.pk_variant);
+        else        snprintf(name, name_len, "sw128_pk_kernel<%d,%d,%d>", mode, cfg.pk_variant, L);
         per_wave = 128 / L;
     } else if (cfg.fold_gap && cfg.use_lut && L >= 4 && L <= 16) {
         snprintf(name, name_len, "sw128_lut_kernel<%d,%d>", L, mode);
@@ -582,6 +714,14 @@ int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq
     return device_entry(d_seq1s_packed, d_seq2s_packed, n, score_matrix, gap_penalty, d_scores, stream, true);
 }
 
+static swmi::SgTuning sg_tuning()
+{
+    swmi::SgTuning t;
+    t.force_sweep = knobs().sg_sweep;
+    t.force_traceback = knobs().sg_traceback;
+    return t;
+}
+
 static int check_banded(const int8_t *sm, int len, int open, int ext)
 {
     if (!sm) return fail(SWMI_ERR_INVALID_ARGUMENT, "score_matrix is NULL");
@@ -600,7 +740,8 @@ static int banded_device(Context &ctx, const void *d_seq1s, const void *d_seq2s,
         const size_t m = n - off < max_launch ? n - off : max_launch;
         HIP_TRY(swmi::launch_banded_affine(static_cast<const uint8_t *>(d_seq1s) + off * size_t(len),
                                            static_cast<const uint8_t *>(d_seq2s) + off * size_t(len),
-                                           static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend, stream));
+                                           static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend, stream,
+                                           !knobs().banded_no_i16));
     }
     return SWMI_OK;
 }
@@ -686,7 +827,7 @@ static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n,
     }
     HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n, ws.ptr,
                                     static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks), cap,
-                                    static_cast<uint32_t *>(d_lengths), st, between, ctx->prop.multiProcessorCount));
+                                    static_cast<uint32_t *>(d_lengths), st, between, ctx->prop.multiProcessorCount, sg_tuning()));
     return SWMI_OK;
 }
 
@@ -712,7 +853,7 @@ int swmi_semiglobal_kernels_for_batch(size_t n, char *sweep, size_t sweep_len, c
 {
     Context *ctx = current();
     if (!ctx) return last_status();
-    swmi::semiglobal_kernel_names(n, ctx->prop.multiProcessorCount, sweep, sweep_len, traceback, traceback_len);
+    swmi::semiglobal_kernel_names(n, ctx->prop.multiProcessorCount, sweep, sweep_len, traceback, traceback_len, sg_tuning());
     return SWMI_OK;
 }
 
@@ -810,7 +951,7 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
         e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st, nullptr, ctx->prop.multiProcessorCount);
+            e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st, nullptr, ctx->prop.multiProcessorCount, sg_tuning());
         if (e == hipSuccess && n_sets == 2) e = drain(turn ^ 1);         // the previous chunk, while this one computes
     }
     for (int k = 0; k < n_sets; ++k) {
@@ -844,6 +985,40 @@ int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
         if (e == hipSuccess) e = es;
     }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_unpack: %s", hipGetErrorString(e));
+    return SWMI_OK;
+}
+
+size_t swmi_host_granules(size_t n, size_t *granules, size_t cap)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_init_mu);
+        if (!g_knobs_read) read_knobs();
+    }
+    size_t count = 0;
+    for (size_t group = 0; group < n; group += kScoreGroup) {
+        const size_t group_n = n - group < kScoreGroup ? n - group : kScoreGroup;
+        for (size_t off = 0; off < group_n; ++count) {
+            const size_t m = next_granule(group_n - off);
+            if (granules && count < cap) granules[count] = m;
+            off += m;
+        }
+    }
+    return count;
+}
+
+int swmi_selftest_pk_max3(unsigned long long *checked, unsigned long long *mismatches)
+{
+    if (!checked || !mismatches) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL output");
+    Context *ctx = current();
+    if (!ctx) return last_status();
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    // the pinned, device-visible staging buffer doubles as the two counters (zeroed by the host, added to by the kernel)
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(ctx->pin);
+    h[0] = h[1] = 0;
+    HIP_TRY(swmi::launch_pk_max3_selftest(static_cast<unsigned long long *>(ctx->pin_dev), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *checked = h[0];
+    *mismatches = h[1];
     return SWMI_OK;
 }
 
@@ -921,7 +1096,8 @@ int swmi_queue_create(size_t max_pairs, const int8_t score_matrix[16], int8_t ga
     if (!ctx) return last_status();
     swmi_queue *q = new (std::nothrow) swmi_queue;
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "out of host memory");
-    q->ctx = ctx;
+    q->ctx = context_ref(ctx->index);
+    q->device = ctx->device;
     q->max_pairs = max_pairs;
     memcpy(q->sm, score_matrix, 16);
     q->gap = gap_penalty;
@@ -958,7 +1134,9 @@ long long swmi_queue_submit(swmi_queue *q, const uint8_t seq1[SWMI_SEQ_LEN], con
 int swmi_queue_wait(swmi_queue *q, const int32_t **scores, size_t *n_scores)
 {
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "queue is NULL");
-    int rc = queue_ship(q, q->count);
+    int rc = check_alive(*q->ctx);
+    if (rc != SWMI_OK) return rc;
+    rc = queue_ship(q, q->count);
     const hipError_t es = hipStreamSynchronize(q->stream);       // on failure too: shipments in flight read the staging memory
     if (rc != SWMI_OK) return rc;
     if (es != hipSuccess) return fail(SWMI_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
@@ -970,6 +1148,8 @@ int swmi_queue_wait(swmi_queue *q, const int32_t **scores, size_t *n_scores)
 int swmi_queue_reset(swmi_queue *q)
 {
     if (!q) return fail(SWMI_ERR_INVALID_ARGUMENT, "queue is NULL");
+    const int alive = check_alive(*q->ctx);
+    if (alive != SWMI_OK) return alive;
     HIP_TRY(hipStreamSynchronize(q->stream));
     q->count = q->shipped = 0;
     return SWMI_OK;
@@ -978,7 +1158,7 @@ int swmi_queue_reset(swmi_queue *q)
 int swmi_queue_destroy(swmi_queue *q)
 {
     if (!q) return SWMI_OK;
-    if (q->ctx) (void)hipSetDevice(q->ctx->device);
+    if (q->device >= 0) (void)hipSetDevice(q->device);     // (valid after swmi_shutdown too: the queue owns its stream and buffers)
     if (q->stream) (void)hipStreamSynchronize(q->stream);
     if (q->h_seq1) (void)hipHostFree(q->h_seq1);
     if (q->h_seq2) (void)hipHostFree(q->h_seq2);

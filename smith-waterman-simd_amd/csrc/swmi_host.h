@@ -14,10 +14,31 @@ namespace swmi {
 namespace host {
 
 constexpr size_t kSeq = SWMI_SEQ_LEN;
-constexpr size_t kChunkPairs = size_t(1) << 20;      // host-batch pipeline granule: 1M pairs = 128 MiB per input array
+constexpr size_t kChunkPairs = size_t(1) << 20;      // largest host-batch pipeline granule: 1M pairs = 128 MiB per input array
+constexpr size_t kMinGranule = size_t(1) << 14;      // smallest one (the tail of a tapered schedule)
+constexpr size_t kScoreGroup = size_t(1) << 24;      // pairs whose scores return to the host in one copy (64 MiB)
 constexpr size_t kMaxLaunchPairs = size_t(1) << 30;  // pairs per kernel launch (the kernel indexes pairs with uint32)
-constexpr int kSlots = 2;
+constexpr int kSlots = 3;
 constexpr size_t kPinPairs = 64;                     // host batches up to this size go through the pinned staging buffer
+
+// SWMI_* environment knobs -- experiment / rehearsal switches, none needed in production.  Read ONCE, by swmi_init*
+// (under the init mutex) or by the first call that needs one before any init; never on a launch path (getenv is not safe
+// against a concurrent setenv, and a launch should not pay for it).
+struct Knobs {
+    size_t host_granule = 0;        // SWMI_HOST_GRANULE: fixed pipeline granule in pairs (0 = tapered schedule)
+    bool host_serial = false;       // SWMI_HOST_SERIAL=1: round 2's pipeline (scores copied back behind every granule), for the A/B
+    unsigned extra_lds = 0;         // SWMI_EXTRA_LDS: unused dynamic LDS per workgroup (occupancy sweep, BASELINE config 3)
+    int lanes = 0;                  // SWMI_LANES: initial schedule
+    bool banded_no_i16 = false;     // SWMI_BANDED_NO_I16
+    int sg_sweep = -1;              // SWMI_SG_SWEEP: force a semi-global sweep mapping (sg_kernels.hip choose_sweep)
+    int sg_traceback = -1;          // SWMI_SG_TRACEBACK: 1 = lane-per-walk traceback, 0 = wavefront-per-walk
+    bool gather_p2p = false;        // SWMI_GATHER_BACKEND=p2p: never RCCL
+    size_t gather_piece = 0;        // SWMI_TEST_GATHER_PIECE: ragged RCCL gather even for equal shards, shards broadcast in
+                                    //   pieces of this many scores (rehearses the ragged path with one rank)
+    char rccl_lib[256] = "";        // SWMI_RCCL_LIB: library to dlopen instead of librccl.so (a missing one rehearses the fallback)
+};
+const Knobs &knobs();
+void read_knobs();                  // (re)reads the environment; callers hold the init mutex
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -46,9 +67,15 @@ struct Workspace {
 struct Context {
     int index = 0;                      // position in the bound list = the argument of swmi_use_gpu
     int device = -1;                    // HIP ordinal
+    // swmi_shutdown() releases everything below and sets `dead`; the object itself lives as long as a handle (queue,
+    // sharded batch) still points at it, so that a late *_destroy or a call on a stale handle finds a flag, not freed memory
+    std::atomic<bool> dead{false};
     hipDeviceProp_t prop{};
     hipStream_t stream = nullptr;       // library-owned stream (per-pair path, helpers)
     Slot slots[kSlots];
+    int32_t *d_scores_all = nullptr;    // host-batch pipeline: scores of one group of granules (up to kScoreGroup pairs)
+    size_t scores_all_capacity = 0;
+    hipEvent_t slot_done[kSlots] = {};  // recorded behind a slot's last kernel of a group
     SgSet sg_sets[2];
     // Semi-global device entry: one workspace per caller stream, so that calls on different streams may be in flight at
     // once; a workspace only grows (after synchronising ITS stream), and is looked up, grown and handed to the launch
@@ -68,6 +95,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int last_status();                      // the code the last fail() on this thread returned
 Context *current();                     // the calling thread's context, made current on its device; nullptr + last_status()
 Context *context_at(int index);         // nullptr if out of range
+std::shared_ptr<Context> context_ref(int index);   // what a handle keeps
+int check_alive(const Context &ctx);    // SWMI_OK, or SWMI_ERR_NOT_INITIALIZED when swmi_shutdown() ran after the handle was made
 int num_contexts();
 std::mutex &init_mutex();
 

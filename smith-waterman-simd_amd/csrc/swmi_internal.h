@@ -27,6 +27,8 @@ struct LaunchConfig {
     bool use_lut;              // LDS score lookup instead of v_dot4 (gap-folded body only, L in {16, 8, 4})
     bool use_pk;               // L = 4, 8 or 16, no other variant asked for: packed kernel, two alignments per register;
     int pk_bias;               //   rows then hold s + gap + pk_bias (bytes 0..255), pk_bias = max(0, -(min s + gap))
+    int pk_variant;            //   cell body: 0 = no bias needed, 1 = biased, 2 = vertical-offset form (rows hold s + 2 gap);
+                               //   sw_kernels.hip PkVariant
 };
 
 // Score n pairs resident in device memory. packed = 2-bit inputs (32 B per sequence).
@@ -37,20 +39,31 @@ hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_se
                                     int32_t *d_scores, size_t n_seq1, const SmRows &rows, int gap, hipStream_t stream);
 // Banded (128 diagonals) affine-gap local alignment of n pairs of `len`-mers (device pointers).
 hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
-                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream);
+                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream,
+                                bool allow_i16 = true);     // false: never the 16-bit-max build (SWMI_BANDED_NO_I16, A/B)
 hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,
                            hipStream_t stream);
+// Exhaustive check that v_pk_maximum3_f16 is a packed integer max on [0, 0x7C00)^2 (d_counts: two zeroed 64-bit words:
+// comparisons made, comparisons that failed).
+hipError_t launch_pk_max3_selftest(unsigned long long *d_counts, hipStream_t stream);
 hipError_t launch_unpack(const uint8_t *d_packed, uint8_t *d_unpacked, size_t n_seqs, hipStream_t stream);
 
 bool schedule_supported(int lanes_per_alignment);
 
 // Semi-global adaptive-band X-drop aligner (sg_kernels.hip). Workspace: codes + band rows + summaries for n alignments.
 size_t semiglobal_workspace_bytes(size_t n);
+// Experiment switches of the mapping choice (read from SWMI_SG_SWEEP / SWMI_SG_TRACEBACK once, at swmi_init): -1 = automatic
+struct SgTuning {
+    int force_sweep = -1;        // 0, G or 10 * G + W (sg_kernels.hip choose_sweep)
+    int force_traceback = -1;    // 1 = one lane per walk (+ expand), 0 = one wavefront per walk
+};
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
                              hipEvent_t between = nullptr,    // recorded between the sweep and the traceback kernel
-                             int compute_units = 256);        // of the device: picks the sweep mapping (wavefronts per SIMD)
+                             int compute_units = 256,         // of the device: picks the sweep mapping (wavefronts per SIMD)
+                             SgTuning tuning = SgTuning());
 // Names of the sweep / traceback kernels launch_semiglobal picks for n alignments on a device with that many CUs.
-void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len);
+void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len,
+                             SgTuning tuning = SgTuning());
 
 }  // namespace swmi

@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -43,15 +44,20 @@ bool load_rccl()
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.tried) return g_rccl.handle != nullptr;
     g_rccl.tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.handle) break;
+    const char *override_lib = knobs().rccl_lib[0] ? knobs().rccl_lib : nullptr;       // SWMI_RCCL_LIB
+    const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char *const *names = override_lib ? &override_lib : defaults;
+    const int n_names = override_lib ? 1 : 3;
+    for (int k = 0; k < n_names && !g_rccl.handle; ++k) {
+        (void)dlerror();
+        g_rccl.handle = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+        if (!g_rccl.handle) {
+            const char *err = dlerror();            // ONE call: dlerror() clears the state it returns
+            g_rccl.why = err ? err : "librccl.so not found";
+        }
     }
-    if (!g_rccl.handle) {
-        g_rccl.why = dlerror() ? dlerror() : "librccl.so not found";
-        return false;
-    }
+    if (!g_rccl.handle) return false;
+    g_rccl.why.clear();
     auto sym = [&](const char *nm) { return dlsym(g_rccl.handle, nm); };
     g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
@@ -95,7 +101,8 @@ int multi_host(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm,
         shard_bounds(n, g, G, &lo, &hi);
         if (hi == lo) continue;
         threads.emplace_back([=, &rcs, &errs] {
-            Context *ctx = context_at(g);
+            const std::shared_ptr<Context> keep = context_ref(g);      // (a racing swmi_shutdown is the caller's bug, but it must not free this)
+            Context *ctx = keep.get();
             const hipError_t e = hipSetDevice(ctx->device);      // per host thread, like every HIP "current device"
             if (e != hipSuccess) {
                 rcs[g] = SWMI_ERR_HIP;
@@ -118,7 +125,8 @@ struct swmi_sharded_batch {
     size_t n = 0;
     bool packed = false;
     struct Part {
-        Context *ctx = nullptr;
+        std::shared_ptr<Context> ctx;   // kept alive past swmi_shutdown (Context::dead); launches read its settings
+        int device = -1;                // HIP ordinal: all that swmi_sharded_destroy needs
         size_t lo = 0, hi = 0;
         uint8_t *d1 = nullptr, *d2 = nullptr;
         int32_t *d_scores = nullptr;
@@ -129,38 +137,61 @@ struct swmi_sharded_batch {
     std::vector<Part> parts;
     std::vector<ncclComm_t> comms;      // one per part (single-process RCCL), created on the first GATHER_ALL
     bool rccl_usable = false, rccl_decided = false;
+    std::string rccl_why;               // why SWMI_GATHER_ALL runs on peer copies, when it does
     bool equal_shards = false;
+    size_t piece = 0;                   // ragged RCCL gather: scores per broadcast (0 = a shard at a time)
 };
 
 namespace {
+
+int batch_alive(const swmi_sharded_batch *b)
+{
+    for (const auto &p : b->parts) {
+        const int rc = check_alive(*p.ctx);
+        if (rc != SWMI_OK) return rc;
+    }
+    return SWMI_OK;
+}
 
 int ensure_gathered(swmi_sharded_batch *b, int g)
 {
     auto &p = b->parts[g];
     if (p.d_gathered) return SWMI_OK;
-    SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+    SWMI_HIP_TRY(hipSetDevice(p.device));
     SWMI_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p.d_gathered), (b->n ? b->n : 1) * sizeof(int32_t)));
     return SWMI_OK;
 }
 
 // RCCL needs one communicator rank per DISTINCT device; a GPU bound twice (rehearsal) falls back to peer copies.
+// The reason stays with the batch (swmi_sharded_gather_note) and goes to swmi_last_error() of the deciding call.
 void decide_rccl(swmi_sharded_batch *b)
 {
     if (b->rccl_decided) return;
     b->rccl_decided = true;
     const int G = (int)b->parts.size();
-    const char *env = getenv("SWMI_GATHER_BACKEND");             // "p2p" forces peer copies, "rccl" (default) tries RCCL first
-    if (env && strcmp(env, "p2p") == 0) return;
+    if (knobs().gather_p2p) {                                    // SWMI_GATHER_BACKEND=p2p
+        b->rccl_why = "SWMI_GATHER_BACKEND=p2p";
+        return;
+    }
     std::vector<int> devs(G);
     for (int g = 0; g < G; ++g) {
-        devs[g] = b->parts[g].ctx->device;
+        devs[g] = b->parts[g].device;
         for (int k = 0; k < g; ++k)
-            if (devs[k] == devs[g]) return;
+            if (devs[k] == devs[g]) {
+                b->rccl_why = "device " + std::to_string(devs[g]) + " is bound twice: RCCL needs one rank per distinct device";
+                return;
+            }
     }
-    if (!load_rccl()) return;
+    if (!load_rccl()) {
+        b->rccl_why = "librccl could not be loaded: " + g_rccl.why;
+        return;
+    }
     b->comms.assign(G, nullptr);
     const ncclResult_t r = g_rccl.CommInitAll(b->comms.data(), G, devs.data());
     if (r != ncclSuccess) {
+        b->rccl_why = std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(r);
+        for (ncclComm_t c : b->comms)                            // whatever part of the clique was created
+            if (c) (void)g_rccl.CommDestroy(c);
         b->comms.clear();
         return;
     }
@@ -174,7 +205,7 @@ int score_once(swmi_sharded_batch *b, const int8_t *sm, int gap, int gather, int
     for (int g = 0; g < G; ++g) {
         auto &p = b->parts[g];
         const size_t m = p.hi - p.lo;
-        SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+        SWMI_HIP_TRY(hipSetDevice(p.device));
         hipEvent_t *ev = iter_for_events >= 0 ? &p.ev[3 * size_t(iter_for_events)] : nullptr;
         if (ev) SWMI_HIP_TRY(hipEventRecord(ev[0], p.stream));
         if (m) {
@@ -189,13 +220,13 @@ int score_once(swmi_sharded_batch *b, const int8_t *sm, int gap, int gather, int
             auto &p = b->parts[g];
             const size_t m = p.hi - p.lo;
             if (!m) continue;
-            SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+            SWMI_HIP_TRY(hipSetDevice(p.device));
             for (int r = 0; r < targets; ++r) {                  // push: the copy runs on the SOURCE GPU's stream, behind its kernel
                 auto &dst = b->parts[r];
-                if (dst.ctx->device == p.ctx->device)
+                if (dst.device == p.device)
                     SWMI_HIP_TRY(hipMemcpyAsync(dst.d_gathered + p.lo, p.d_scores, m * sizeof(int32_t), hipMemcpyDeviceToDevice, p.stream));
                 else
-                    SWMI_HIP_TRY(hipMemcpyPeerAsync(dst.d_gathered + p.lo, dst.ctx->device, p.d_scores, p.ctx->device,
+                    SWMI_HIP_TRY(hipMemcpyPeerAsync(dst.d_gathered + p.lo, dst.device, p.d_scores, p.device,
                                                     m * sizeof(int32_t), p.stream));
             }
         }
@@ -205,11 +236,16 @@ int score_once(swmi_sharded_batch *b, const int8_t *sm, int gap, int gather, int
             auto &p = b->parts[g];
             if (b->equal_shards) {
                 r = g_rccl.AllGather(p.d_scores, p.d_gathered, p.hi - p.lo, ncclInt32, b->comms[g], p.stream);
-            } else {                                             // ragged shards: one broadcast per non-empty shard, same order on every rank
+            } else {                                             // ragged shards: broadcasts per non-empty shard, same order on every rank
                 for (int root = 0; root < G && r == ncclSuccess; ++root) {
                     const auto &src = b->parts[root];
-                    if (src.hi == src.lo) continue;
-                    r = g_rccl.Broadcast(p.d_scores, p.d_gathered + src.lo, src.hi - src.lo, ncclInt32, root, b->comms[g], p.stream);
+                    const size_t m = src.hi - src.lo, piece = b->piece ? b->piece : m;      // (pieces: SWMI_TEST_GATHER_PIECE)
+                    for (size_t off = 0; off < m && r == ncclSuccess; off += piece) {
+                        const size_t cnt = m - off < piece ? m - off : piece;
+                        // the send buffer is read on the root only; every rank passes its own shard pointer (offset as on the root)
+                        r = g_rccl.Broadcast(p.d_scores + (g == root ? off : 0), p.d_gathered + src.lo + off, cnt, ncclInt32, root,
+                                             b->comms[g], p.stream);
+                    }
                 }
             }
         }
@@ -220,7 +256,7 @@ int score_once(swmi_sharded_batch *b, const int8_t *sm, int gap, int gather, int
     if (iter_for_events >= 0)
         for (int g = 0; g < G; ++g) {
             auto &p = b->parts[g];
-            SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+            SWMI_HIP_TRY(hipSetDevice(p.device));
             SWMI_HIP_TRY(hipEventRecord(p.ev[3 * size_t(iter_for_events) + 2], p.stream));
         }
     return SWMI_OK;
@@ -232,7 +268,11 @@ int prepare_gather(swmi_sharded_batch *b, int gather)
         return fail(SWMI_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
     if (gather == SWMI_GATHER_ROOT) return ensure_gathered(b, 0);
     if (gather == SWMI_GATHER_ALL) {
+        const bool deciding = !b->rccl_decided;
         decide_rccl(b);
+        // not an error -- the gather runs on peer copies and gives the same bytes -- but never silent: the text is what
+        // swmi_last_error() returns after this call, and swmi_sharded_gather_note() keeps it
+        if (deciding && !b->rccl_usable) (void)fail(SWMI_OK, "SWMI_GATHER_ALL runs on peer copies, not RCCL: %s", b->rccl_why.c_str());
         for (int g = 0; g < (int)b->parts.size(); ++g) {
             const int rc = ensure_gathered(b, g);
             if (rc != SWMI_OK) return rc;
@@ -245,7 +285,7 @@ int wait_all(swmi_sharded_batch *b)
 {
     hipError_t e = hipSuccess;
     for (auto &p : b->parts) {
-        hipError_t es = hipSetDevice(p.ctx->device);
+        hipError_t es = hipSetDevice(p.device);
         if (es == hipSuccess) es = hipStreamSynchronize(p.stream);
         if (e == hipSuccess) e = es;
     }
@@ -288,16 +328,18 @@ int swmi_sharded_create(size_t n, int packed, swmi_sharded_batch **out)
     if (!b) return fail(SWMI_ERR_INVALID_ARGUMENT, "out of host memory");
     b->n = n;
     b->packed = packed != 0;
-    b->equal_shards = n % size_t(G) == 0 && n > 0;
+    b->piece = knobs().gather_piece;                           // rehearsal: the ragged RCCL path even with equal shards / one rank
+    b->equal_shards = n % size_t(G) == 0 && n > 0 && b->piece == 0;
     b->parts.resize(G);
     const size_t stride = b->packed ? SWMI_PACKED_LEN : kSeq;
     hipError_t e = hipSuccess;
     for (int g = 0; g < G && e == hipSuccess; ++g) {
         auto &p = b->parts[g];
-        p.ctx = context_at(g);
+        p.ctx = context_ref(g);
+        p.device = p.ctx->device;
         shard_bounds(n, g, G, &p.lo, &p.hi);
         const size_t m = p.hi - p.lo ? p.hi - p.lo : 1;
-        e = hipSetDevice(p.ctx->device);
+        e = hipSetDevice(p.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p.d1), m * stride);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p.d2), m * stride);
@@ -314,16 +356,17 @@ int swmi_sharded_create(size_t n, int packed, swmi_sharded_batch **out)
 int swmi_sharded_destroy(swmi_sharded_batch *b)
 {
     if (!b) return SWMI_OK;
+    // valid after swmi_shutdown() too: the batch owns its streams, buffers and communicators; only the device ordinal is needed
     for (auto &p : b->parts) {
-        if (!p.ctx) continue;
-        (void)hipSetDevice(p.ctx->device);
+        if (p.device < 0) continue;
+        (void)hipSetDevice(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
     }
     for (ncclComm_t c : b->comms)
         if (c) (void)g_rccl.CommDestroy(c);
     for (auto &p : b->parts) {
-        if (!p.ctx) continue;
-        (void)hipSetDevice(p.ctx->device);
+        if (p.device < 0) continue;
+        (void)hipSetDevice(p.device);
         for (hipEvent_t ev : p.ev) (void)hipEventDestroy(ev);
         (void)hipFree(p.d1); (void)hipFree(p.d2); (void)hipFree(p.d_scores); (void)hipFree(p.d_gathered);
         if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -336,9 +379,10 @@ int swmi_sharded_generate(swmi_sharded_batch *b, uint64_t seed, uint64_t first_p
 {
     if (!b) return fail(SWMI_ERR_INVALID_ARGUMENT, "batch is NULL");
     if (b->packed) return fail(SWMI_ERR_INVALID_ARGUMENT, "the generator writes one base per byte; create the batch with packed = 0");
+    if (batch_alive(b) != SWMI_OK) return last_status();
     for (auto &p : b->parts) {
         if (p.hi == p.lo) continue;
-        SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+        SWMI_HIP_TRY(hipSetDevice(p.device));
         SWMI_HIP_TRY(swmi::launch_generate(p.d1, p.d2, p.hi - p.lo, seed, first_pair + p.lo, p.stream));
     }
     return SWMI_OK;
@@ -347,11 +391,12 @@ int swmi_sharded_generate(swmi_sharded_batch *b, uint64_t seed, uint64_t first_p
 int swmi_sharded_upload(swmi_sharded_batch *b, const uint8_t *seq1s, const uint8_t *seq2s)
 {
     if (!b || !seq1s || !seq2s) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (batch_alive(b) != SWMI_OK) return last_status();
     const size_t stride = b->packed ? SWMI_PACKED_LEN : kSeq;
     hipError_t e = hipSuccess;
     for (auto &p : b->parts) {
         if (p.hi == p.lo || e != hipSuccess) continue;
-        e = hipSetDevice(p.ctx->device);
+        e = hipSetDevice(p.device);
         if (e == hipSuccess) e = hipMemcpyAsync(p.d1, seq1s + p.lo * stride, (p.hi - p.lo) * stride, hipMemcpyHostToDevice, p.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(p.d2, seq2s + p.lo * stride, (p.hi - p.lo) * stride, hipMemcpyHostToDevice, p.stream);
     }
@@ -365,6 +410,7 @@ int swmi_sharded_score(swmi_sharded_batch *b, const int8_t score_matrix[16], int
     if (!b) return fail(SWMI_ERR_INVALID_ARGUMENT, "batch is NULL");
     int rc = check_params(score_matrix, gap_penalty);
     if (rc != SWMI_OK) return rc;
+    if (batch_alive(b) != SWMI_OK) return last_status();
     rc = prepare_gather(b, gather);
     if (rc != SWMI_OK) return rc;
     return score_once(b, score_matrix, gap_penalty, gather, -1);
@@ -373,16 +419,18 @@ int swmi_sharded_score(swmi_sharded_batch *b, const int8_t score_matrix[16], int
 int swmi_sharded_wait(swmi_sharded_batch *b)
 {
     if (!b) return fail(SWMI_ERR_INVALID_ARGUMENT, "batch is NULL");
+    if (batch_alive(b) != SWMI_OK) return last_status();
     return wait_all(b);
 }
 
 int swmi_sharded_scores_host(swmi_sharded_batch *b, int32_t *scores)
 {
     if (!b || (!scores && b->n)) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (batch_alive(b) != SWMI_OK) return last_status();
     hipError_t e = hipSuccess;
     for (auto &p : b->parts) {
         if (p.hi == p.lo || e != hipSuccess) continue;
-        e = hipSetDevice(p.ctx->device);
+        e = hipSetDevice(p.device);
         if (e == hipSuccess) e = hipMemcpyAsync(scores + p.lo, p.d_scores, (p.hi - p.lo) * sizeof(int32_t), hipMemcpyDeviceToHost, p.stream);
     }
     const int rc = wait_all(b);
@@ -404,15 +452,34 @@ int swmi_sharded_gather_backend(swmi_sharded_batch *b)
     return !b->rccl_decided ? 0 : b->rccl_usable ? 2 : 1;
 }
 
+int swmi_sharded_gather_note(swmi_sharded_batch *b, char *text, size_t text_len)
+{
+    if (!b || !text || text_len == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL argument");
+    snprintf(text, text_len, "%s", b->rccl_why.c_str());
+    return SWMI_OK;
+}
+
+int swmi_rccl_probe(char *why, size_t why_len)
+{
+    {
+        std::lock_guard<std::mutex> lock(init_mutex());
+        if (num_contexts() == 0) read_knobs();          // before any init: take SWMI_RCCL_LIB from the environment now
+    }
+    const bool ok = load_rccl();
+    if (why && why_len) snprintf(why, why_len, "%s", ok ? "" : g_rccl.why.c_str());
+    return ok ? 1 : 0;
+}
+
 int swmi_sharded_gathered_host(swmi_sharded_batch *b, int index, int32_t *scores)
 {
     void *d = nullptr;
     const int rc = swmi_sharded_gathered_device(b, index, &d);
     if (rc != SWMI_OK) return rc;
     if (!scores && b->n) return fail(SWMI_ERR_INVALID_ARGUMENT, "scores is NULL");
+    if (batch_alive(b) != SWMI_OK) return last_status();
     const int rw = wait_all(b);         // the gather into this GPU runs on the OTHER GPUs' streams
     if (rw != SWMI_OK) return rw;
-    SWMI_HIP_TRY(hipSetDevice(b->parts[index].ctx->device));
+    SWMI_HIP_TRY(hipSetDevice(b->parts[index].device));
     SWMI_HIP_TRY(hipMemcpy(scores, d, b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return SWMI_OK;
 }
@@ -423,10 +490,11 @@ int swmi_sharded_time(swmi_sharded_batch *b, const int8_t score_matrix[16], int8
     if (!b || iters <= 0 || iters > 100000) return fail(SWMI_ERR_INVALID_ARGUMENT, "batch is NULL or iters outside [1, 100000]");
     int rc = check_params(score_matrix, gap_penalty);
     if (rc != SWMI_OK) return rc;
+    if (batch_alive(b) != SWMI_OK) return last_status();
     rc = prepare_gather(b, gather);
     if (rc != SWMI_OK) return rc;
     for (auto &p : b->parts) {
-        SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+        SWMI_HIP_TRY(hipSetDevice(p.device));
         while (p.ev.size() < 3 * size_t(iters)) {
             hipEvent_t ev = nullptr;
             SWMI_HIP_TRY(hipEventCreate(&ev));
@@ -444,7 +512,7 @@ int swmi_sharded_time(swmi_sharded_batch *b, const int8_t score_matrix[16], int8
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
     for (size_t g = 0; g < b->parts.size(); ++g) {
         auto &p = b->parts[g];
-        SWMI_HIP_TRY(hipSetDevice(p.ctx->device));
+        SWMI_HIP_TRY(hipSetDevice(p.device));
         double k = 0, ga = 0;
         for (int it = 0; it < iters; ++it) {
             float a = 0.f, c = 0.f;

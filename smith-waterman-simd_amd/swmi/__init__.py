@@ -77,6 +77,11 @@ def load():
     lib.swmi_sharded_gathered_host.argtypes = [vp, ctypes.c_int, vp]
     lib.swmi_sharded_time.argtypes = [vp, vp, i8, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+    lib.swmi_host_granules.argtypes = [sz, vp, sz]
+    lib.swmi_host_granules.restype = sz
+    lib.swmi_selftest_pk_max3.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+    lib.swmi_sharded_gather_note.argtypes = [vp, ctypes.c_char_p, sz]
+    lib.swmi_rccl_probe.argtypes = [ctypes.c_char_p, sz]
     lib.swmi_score_kernel_for_batch.argtypes = [sz, vp, i8, ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int)]
     lib.swmi_semiglobal_kernels_for_batch.argtypes = [sz, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
     lib.swmi_score_pair.argtypes = [vp, vp, vp, i8]
@@ -209,6 +214,28 @@ def score_kernel_for_batch(n, score_matrix, gap_penalty, mode=0):
     return name.value.decode(), per_wave.value
 
 
+def selftest_pk_max3():
+    """(comparisons made, mismatches) of swmi_selftest_pk_max3: v_pk_maximum3_f16 as a packed integer max on [0, 0x7C00)^2."""
+    checked, bad = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    _check(load().swmi_selftest_pk_max3(ctypes.byref(checked), ctypes.byref(bad)))
+    return checked.value, bad.value
+
+
+def host_granules(n):
+    """The pipeline granules swmi_score_batch cuts a host batch of n pairs into (needs no device)."""
+    count = load().swmi_host_granules(n, None, 0)
+    buf = (ctypes.c_size_t * max(count, 1))()
+    load().swmi_host_granules(n, buf, count)
+    return [int(buf[k]) for k in range(count)]
+
+
+def rccl_probe():
+    """(usable, reason): whether librccl can be loaded with the entry points the score gather needs (needs no device)."""
+    why = ctypes.create_string_buffer(512)
+    ok = load().swmi_rccl_probe(why, 512)
+    return bool(ok), why.value.decode()
+
+
 def device_info():
     info = DeviceInfo()
     _check(load().swmi_get_device_info(ctypes.byref(info)))
@@ -284,6 +311,12 @@ class ShardedBatch:
 
     def gather_backend(self):
         return {0: "undecided", 1: "p2p", 2: "rccl"}[_check(load().swmi_sharded_gather_backend(self._b))]
+
+    def gather_note(self):
+        """Why SWMI_GATHER_ALL runs on peer copies for this batch ("" while RCCL is in use or nothing is decided)."""
+        text = ctypes.create_string_buffer(512)
+        _check(load().swmi_sharded_gather_note(self._b, text, 512))
+        return text.value.decode()
 
     def gathered(self, index=0):
         """The full score vector GPU `index` holds after a gather, copied to the host."""

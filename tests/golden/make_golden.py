@@ -211,8 +211,15 @@ def main():
     unpacked = np.zeros((256, 128), np.uint8)
     for k in range(256):
         ref.swref_unpack(P(packed[k], u8p), P(unpacked[k], u8p))
+    # one-vs-many with GENERAL parameters (the shape of source.cpp:1227-1230 behind swmi_score_one_vs_many): every seq1 of
+    # F5 against seq2[0], from the reference scalar with the SIMD variants agreeing (score_all).  Draws nothing from rng, so
+    # the fixtures generated after this point are unchanged.
+    ovm_params = [core_params[k] for k in (0, 1, 2, 3, 4, 5, 6, 9)]
+    ovm_sm, ovm_gap = pack_params(ovm_params)
+    ovm_scores = score_all(a5, np.repeat(b5[:1], n5, axis=0), ovm_params)
     np.savez_compressed(os.path.join(HERE, "f5_siblings.npz"), seq1=a5, seq2=b5, scores_111=s111,
-                        scores_111x32=x32, packed=packed, unpacked=unpacked)
+                        scores_111x32=x32, packed=packed, unpacked=unpacked,
+                        ovm_sm=ovm_sm, ovm_gap=ovm_gap, ovm_scores=ovm_scores)
     # F6: semi-global adaptive-band X-drop aligner (source.cpp:1836-2725), SURVEY 8f row N4.  Scalar and the four SIMD
     # variants must return the same (score, traceback); the traceback is stored as one move code per step
     # (1 = diagonal, 2 = down (i+1), 3 = right (j+1)) from (0,0).

@@ -67,6 +67,28 @@ int main()
     CHECK(swmi_sharded_destroy(nullptr) == SWMI_OK);
     CHECK(swmi_sharded_wait(nullptr) == SWMI_ERR_INVALID_ARGUMENT);
 
+    // the host-batch pipeline schedule needs no device: every pair exactly once, tapering
+    {
+        size_t g[64];
+        CHECK(swmi_host_granules(0, g, 64) == 0);
+        const size_t c = swmi_host_granules(size_t(1) << 20, g, 64);
+        CHECK(c == 4 && g[0] == 786432 && g[1] == 196608 && g[2] == 49152 && g[3] == 16384);
+        size_t total = 0;
+        const size_t c2 = swmi_host_granules((size_t(1) << 24) + 777, g, 2);     // more granules than the array holds
+        CHECK(c2 > 2 && g[0] == size_t(1) << 20);
+        (void)total;
+    }
+    // librccl is loaded on first use; the probe needs no device.  SWMI_RCCL_LIB naming a missing file rehearses the failure
+    // path (tests/test_sanitizers.py runs this program a second time that way)
+    {
+        char why[256] = "x";
+        const int usable = swmi_rccl_probe(why, sizeof why);
+        if (getenv("SWMI_RCCL_LIB")) CHECK(usable == 0 && strlen(why) > 0);
+        else CHECK(usable == 0 || (usable == 1 && strlen(why) == 0));
+        CHECK(swmi_rccl_probe(nullptr, 0) == usable);
+    }
+    CHECK(swmi_sharded_gather_note(nullptr, nullptr, 0) == SWMI_ERR_INVALID_ARGUMENT);
+
     // before init: everything that needs a device says so (no CPU fallback)
     CHECK(swmi_num_gpus() == 0);
     CHECK(swmi_score_batch(a.data(), b.data(), 70, sm, 15, out.data()) == SWMI_ERR_NOT_INITIALIZED);
@@ -125,6 +147,15 @@ int main()
         CHECK(swmi_queue_submit(q, a.data(), b.data()) == 0);
         CHECK(swmi_queue_destroy(q) == SWMI_OK);
         CHECK(swmi_sharded_create(1000, 0, &sb) == SWMI_OK);
+        CHECK(swmi_sharded_destroy(sb) == SWMI_OK);
+        // handles that outlive swmi_shutdown(): calls fail cleanly, destroy still works (no use of freed contexts)
+        CHECK(swmi_queue_create(16, sm, 15, &q) == SWMI_OK);
+        CHECK(swmi_sharded_create(1000, 0, &sb) == SWMI_OK);
+        CHECK(swmi_shutdown() == SWMI_OK);
+        CHECK(swmi_queue_wait(q, nullptr, nullptr) == SWMI_ERR_NOT_INITIALIZED);
+        CHECK(swmi_sharded_score(sb, sm, 15, SWMI_GATHER_NONE) == SWMI_ERR_NOT_INITIALIZED);
+        CHECK(swmi_sharded_wait(sb) == SWMI_ERR_NOT_INITIALIZED);
+        CHECK(swmi_queue_destroy(q) == SWMI_OK);
         CHECK(swmi_sharded_destroy(sb) == SWMI_OK);
     }
     CHECK(swmi_shutdown() == SWMI_OK);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(PKG, "lib", "libswmi.so"))
     for name in _declared_symbols():
         assert hasattr(lib, name), "libswmi.so does not export %s" % name
-    assert lib.swmi_version() == 200
+    assert lib.swmi_version() == 300
 
 
 def test_product_library_does_not_link_the_oracle():
@@ -80,19 +80,26 @@ def test_c_shard_rule_is_the_python_shard_rule(swmi_mod):
 
 def test_kernel_choice_is_reported_without_a_device(swmi_mod):
     """swmi_score_kernel_for_batch: which kernel instantiation a launch runs (what bench.py prices with tools/isa_census.py).
-    L = 4, 8 and 16 run the packed kernel (two alignments per register; 32 / 16 / 8 alignments per wavefront), in its bias
-    form only when some folded score s + gap is negative; flag 8 and the other lane counts run the int32 kernel; small batches
-    take more lanes."""
+    L = 4, 8 and 16 run the packed kernel (two alignments per register; 32 / 16 / 8 alignments per wavefront) -- cell body 0
+    when every score + gap >= 0, 2 (vertical offsets) when every score + 2 gap >= 0 and the offsets fit, 1 (biased) otherwise;
+    flag 8 and the other lane counts run the int32 kernel; small batches take more lanes."""
     big = 1 << 20
     swmi_mod.set_schedule(0, 0)
     try:
-        assert swmi_mod.score_kernel_for_batch(big, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1>", 32)
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,2>", 32)      # -30 + 2 * 15 = 0
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(1, -1), 1) == ("sw128_pk_kernel<0,0>", 32)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 127, mode=1) == ("sw128_pk_kernel<1,0>", 32)
         assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -128), 0, mode=2) == ("sw128_pk_kernel<2,1>", 32)
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(5, -4), 0) == ("sw128_pk_kernel<0,1>", 32)          # -4 + 0 < 0
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(10, -30), 14) == ("sw128_pk_kernel<0,1>", 32)       # -30 + 28 < 0
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 64) == ("sw128_pk_kernel<0,2>", 32)     # 127 + 128 = 255 fits a byte
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(127, -127), 65) == ("sw128_pk_kernel<0,1>", 32)     # 127 + 130 does not
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(120, -120), 62) == ("sw128_pk_kernel<0,2>", 32)
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(126, -120), 64, mode=2) == ("sw128_pk_kernel<2,2>", 32)
+        assert swmi_mod.score_kernel_for_batch(big, match_matrix(100, -100), 100) == ("sw128_pk_kernel<0,0>", 32)    # every s + gap >= 0
         assert swmi_mod.score_kernel_for_batch(1000, match_matrix(10, -30), 15) == ("sw128_kernel<64,1,0,0>", 1)
-        assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,16>", 8)
-        assert swmi_mod.score_kernel_for_batch(50000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,1,8>", 16)
+        assert swmi_mod.score_kernel_for_batch(10000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,2,16>", 8)
+        assert swmi_mod.score_kernel_for_batch(50000, match_matrix(10, -30), 15) == ("sw128_pk_kernel<0,2,8>", 16)
         # the automatic choice switches where the measured kernel times cross (profiles/r02_small_batch_schedule.txt)
         per_wave = [swmi_mod.score_kernel_for_batch(n, match_matrix(10, -30), 15)[1] for n in (2048, 2049, 5120, 5121, 24576, 24577, 98304, 98305)]
         assert per_wave == [1, 2, 2, 8, 8, 16, 16, 32]
@@ -166,3 +173,39 @@ def test_host_generator_matches_the_oracle_generator(swmi_mod, oracle):
 def test_pack_helper_round_trips(swmi_mod, golden):
     f = golden("f5_siblings")
     assert np.array_equal(swmi_mod.pack(f["unpacked"]), f["packed"])
+
+
+def test_host_batch_granules(swmi_mod):
+    """The pipeline schedule of swmi_score_batch (swmi_api.cpp next_granule): tapering granules, every pair exactly once,
+    few copy commands, a small last granule so that almost no kernel time is left behind the last copy.  Needs no device."""
+    for k in ("SWMI_HOST_GRANULE", "SWMI_HOST_SERIAL"):
+        assert k not in os.environ
+    assert swmi_mod.host_granules(0) == []
+    assert swmi_mod.host_granules(1) == [1]
+    assert swmi_mod.host_granules(16384) == [16384] and swmi_mod.host_granules(5000) == [5000]
+    assert swmi_mod.host_granules(1 << 20) == [786432, 196608, 49152, 16384]
+    assert swmi_mod.host_granules(1 << 22) == [1 << 20, 1 << 20, 1 << 20, 786432, 196608, 49152, 16384]
+    for n in (16385, 65537, 100000, (1 << 20) + 1, 3000001, (1 << 24) + 12345, (1 << 26) + 7):
+        g = swmi_mod.host_granules(n)
+        assert sum(g) == n and max(g) <= 1 << 20 and min(g[:-1] or [1 << 14]) >= 1 << 14
+        assert g[-1] <= 1 << 14 or n <= 1 << 14 or len(g) == 1
+        assert len(g) <= n // (1 << 20) + 16             # a handful of copy commands beyond the 1M-pair granules
+
+
+def test_rccl_probe_reports_a_missing_library(swmi_mod):
+    """load_rccl()'s failure path (swmi_multi.cpp): a library that does not exist must come back as "not usable" with the
+    loader's reason -- round 2 called dlerror() twice there and built a std::string from NULL.  Run in a child process: the
+    library decides once per process which librccl it uses."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import swmi; ok, why = swmi.rccl_probe(); print(int(ok)); print(why)" % PKG)
+    missing = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             env=dict(os.environ, SWMI_RCCL_LIB="/nonexistent/librccl-not-here.so"))
+    assert missing.returncode == 0, missing.stderr
+    lines = missing.stdout.strip().splitlines()
+    assert lines[0] == "0" and "librccl-not-here" in lines[1]
+    present = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             env={k: v for k, v in os.environ.items() if k != "SWMI_RCCL_LIB"})
+    assert present.returncode == 0, present.stderr
+    lines = present.stdout.strip().splitlines()
+    assert lines[0] in ("0", "1") and (lines[0] == "1" or len(lines) > 1)       # this image ships librccl: normally 1

@@ -54,3 +54,8 @@ def test_product_host_code_under_asan_ubsan(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert run.returncode == 0, run.stdout[-3000:]
     assert "abi hostpaths ok" in run.stdout
+    # again with a librccl that cannot be loaded: load_rccl()'s failure path (one dlerror() call, a reason string) under ASan
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", SWMI_RCCL_LIB="/nonexistent/librccl-not-here.so"))
+    assert run.returncode == 0, run.stdout[-3000:]
+    assert "abi hostpaths ok" in run.stdout
