@@ -26,8 +26,19 @@ namespace {
 constexpr int kLen = 16384;                 // std::array<uint8_t,16384>, source.cpp:1837-1838
 constexpr int kXDrop = 70;                  // X_THRESHOLD, source.cpp:1848
 constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
-// per-alignment row strides of the sweep's records, padded so that every alignment starts on a 64-byte line
-constexpr int kCodeStride = (kMaxRound + 15) & ~15;      // uint2 entries (8 B): 262272 B per alignment = 2049 lines of 128 B
+// Predecessor records: 8 bytes per alignment and round, WINDOW-MAJOR: 16 rounds of one alignment = one 128-byte line, and the
+// lines of one window lie side by side for all alignments of the batch:
+//     record of (alignment a, round r) = uint2 index ((r / 16) * n + a) * 16 + (r % 16)
+// Sweeps and walks move through the rounds in lockstep -- every alignment of a wavefront is in the same window at the same
+// time -- so a sweep wavefront's flush (its 32 alignments) and a walk wavefront's fetch (its 64 walks) are ONE contiguous
+// 4 / 8 KB block, written and read with fully coalesced 16-byte accesses.  (Round 2 kept one array per alignment: a walk
+// wavefront's fetch was 64 separate lines 262 KB apart, each requested in 16-byte pieces by one lane: 3.5 TB/s.)
+constexpr int kCodeWindow = 16;                           // rounds per line
+constexpr int kCodeWindows = (kMaxRound + kCodeWindow - 1) / kCodeWindow;
+__device__ __forceinline__ size_t code_index(uint32_t n, uint32_t a, int round)          // in uint2 (one round's record)
+{
+    return ((size_t)(round / kCodeWindow) * n + a) * kCodeWindow + (round % kCodeWindow);
+}
 // move bits: bit (r & 31) of word r >> 5 = 1 when the band stepped right in round r (source.cpp:1895); stored
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
 constexpr int kDirWords = kMaxRound / 32 + 1;
@@ -72,7 +83,7 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 }
 
 // Sweep for small batches: one band cell per lane, two alignments per wavefront.
-// codes[(a * kCodeStride + r)] = the round's two tag words (above); dirs = the band's move bits (above);
+// codes[code_index(n, a, r)] = the round's two tag words (above); dirs = the band's move bits (above);
 // summary[a] = {score, best_round, best_lane (| kTagFormat), row of the band's top cell in best_round}
 //
 // A round is one long dependency chain, and with one wavefront per SIMD or fewer (what a small batch gives) EVERY
@@ -98,7 +109,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     const bool real = a < n;
     if (!real) a = n - 1;                                 // odd tail: shadow the last alignment, store nothing
     const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
-    uint2 *my_codes = reinterpret_cast<uint2 *>(codes) + (size_t)a * kCodeStride;
+    uint2 *all_codes = reinterpret_cast<uint2 *>(codes);
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
     const bool writer = real && k == 0;
     auto pick = [](int m, int if_set, int if_clear) { return (int)__builtin_amdgcn_bitop3_b32((unsigned)m, (unsigned)if_set, (unsigned)if_clear, 0xCA); };
@@ -114,7 +125,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
     int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0;
     bool alive = true;
     unsigned dir_word = 0;                                // move bits of the current 32 rounds: round r enters at bit 31, ends at bit r & 31
-    if (writer) my_codes[0] = make_uint2(0, 0);
+    if (writer) all_codes[code_index(n, a, 0)] = make_uint2(0, 0);
 
     int round = 1;
     for (; round < kMaxRound; ++round) {
@@ -164,7 +175,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
         cur = (int)__builtin_amdgcn_bitop3_b32((unsigned)v0, (unsigned)below_thr, (unsigned)~(kScale - 1), 0xA8);   // (v0 | dropped) & clean
         // the winners' tags, as two ballots: word 0 = low tag bits, word 1 = high tag bits of the 32 band cells
         const unsigned long long t0 = __ballot((v0 & 1) != 0), t1 = __ballot((v0 & 2) != 0);
-        if (writer) my_codes[round] = second ? make_uint2((unsigned)(t0 >> 32), (unsigned)(t1 >> 32)) : make_uint2((unsigned)t0, (unsigned)t1);
+        if (writer) all_codes[code_index(n, a, round)] = second ? make_uint2((unsigned)(t0 >> 32), (unsigned)(t1 >> 32)) : make_uint2((unsigned)t0, (unsigned)t1);
         if ((round & 31) == 31) {                         // (a running pointer: `(round >> 5) * n` would be recomputed every round)
             if (writer) *my_dirs = dir_word;
             my_dirs += n;
@@ -292,7 +303,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             const int fa = q * 8 + (lane >> 3), part = lane & 7;
             const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
             if (block_first + fa < n)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + (size_t)(block_first + fa) * kCodeStride + 16 * g16 + 2 * part) = v;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + block_first + fa) * kCodeWindow + 2 * part) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -518,7 +529,7 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
 {
     const uint32_t a = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint2 *my_codes = reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride;
+    const uint2 *all_codes = reinterpret_cast<const uint2 *>(codes);
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]
     int4 sum = summary[a];
     const bool tag_format = (sum.z & kTagFormat) != 0;      // packed tags (split sweep) / two tag words (half-wavefront sweep)
@@ -538,7 +549,7 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         auto fetch = [&](int b, uint2 &cw, unsigned long long &bits) {       // codes of round b + lane; move bits of rounds b .. b + 63
             const int r = b + lane;
             const bool ok = b >= 0 && r < kMaxRound;
-            cw = ok ? my_codes[r] : make_uint2(0, 0);
+            cw = ok ? all_codes[code_index(n, a, r)] : make_uint2(0, 0);
             const int w = b >> 5;                          // b is a multiple of 64
             const unsigned lo = b >= 0 ? my_dirs[(size_t)w * n] : 0u, hi = (b >= 0 && w + 1 < kDirWords) ? my_dirs[(size_t)(w + 1) * n] : 0u;
             bits = ((unsigned long long)hi << 32) | lo;
@@ -613,54 +624,86 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
 // reached -- but its moves, 2 bits per step (1 diag, 2 up, 3 left), 8 KB per alignment at most.
 //
 // sg_expand_kernel: one wavefront per alignment turns the moves into the (i, j) list of source.cpp:1951-1975, in
-// ascending order from (0,0): position i is the sum of the last i moves of the walk, a prefix sum over the reversed move
-// list -- 256 positions per trip: four independent move fetches first, then four 64-lane prefix sums and four 512-byte
-// stores whose lane 0 sits on a 128-byte line of the output (round 2: one fetch, one store per trip, each trip a full
-// memory latency: 3.4 TB/s of stores).
+// ascending order from (0,0) (see the kernel).
 constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
-constexpr int kWinRounds = 16;                           // rounds per walk window: one 128-byte line of code records
-constexpr int kWinQuads = kWinRounds / 2;                // uint4 = two rounds
+constexpr int kWinQuads = kCodeWindow / 2;               // uint4 = two rounds; 8 per line
+constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uint4 (padded)
 
+// A step of a walk is one dependency chain (LDS read, decode, update of (y, x), next address) and the 65536 walks of the
+// bench batch are 1024 wavefronts, one per SIMD, so the kernel is bound by the instructions of that chain, not by memory:
+// fewer walks per wavefront (more wavefronts per SIMD) made it SLOWER -- 3.79 / 4.16 / 5.76 ms with 64 / 32 / 16 walks per
+// wavefront -- and taking a fifth of the instructions out of the step did not show either: what is left is the latency of that
+// chain, ~555 cycles per step (profiles/r03_sg_traceback_experiments.txt).
+// PACKED = the records hold packed tags (split sweeps) rather than two ballot words per round (half-wavefront sweep).
+template <bool PACKED>
 __global__ void __launch_bounds__(64)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
                     int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
 {
-    __shared__ uint4 line_codes[64][kWinQuads + 1];       // [lane][two rounds], padded
+    constexpr int WALKS = 64;
+    constexpr int kPieces = WALKS / 8;                    // 16-byte pieces per lane and window: 64 lines of 128 bytes over 64 lanes
+    __shared__ uint4 line_codes[WALKS * kLinePitch];      // [walk][two rounds], padded
     const int lane = threadIdx.x;
-    const uint32_t a0 = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t a_first = blockIdx.x * WALKS;
+    const uint32_t a0 = a_first + threadIdx.x;
     const bool real = a0 < n;
     const uint32_t a = real ? a0 : n - 1;                 // tail lanes shadow the last alignment and store nothing
-    const uint4 *my_codes = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(codes) + (size_t)a * kCodeStride);
+    const uint4 *all_codes = reinterpret_cast<const uint4 *>(codes);
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
     unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     int4 sum = summary[a];
-    const bool tag_format = (sum.z & kTagFormat) != 0;      // packed tags (split sweep) / two tag words (half-wavefront sweep)
     sum.z &= 31;
     int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
-    int wmax = sum.y / kWinRounds;
+    int wmax = sum.y / kCodeWindow;
     wmax = row16_max(wmax);
     wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
                max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
 
     bool walking = (y | x) != 0;
     uint32_t steps = 0;
-    unsigned acc_lo = 0, acc_hi = 0;                      // the last (steps & 31) moves, 2 bits each
-    auto load_window = [&](int w, uint4 (&buf)[kWinQuads]) {
-        const int wc = w > 0 ? w : 0;                     // below window 0: window 0 again (no branch around the loads)
-#pragma unroll
-        for (int q = 0; q < kWinQuads; ++q) buf[q] = my_codes[kWinQuads * wc + q];
+    unsigned long long acc = 0;                           // the last (steps & 31) moves, 2 bits each
+    // The WALKS lines of a window (one per walk of this wavefront) lie side by side in memory: the wavefront fetches them
+    // COOPERATIVELY, 1 KB per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 8, quarter p % 8 -- and
+    // hands them to the walks through LDS.  (A ragged last block repeats the batch's last line.)
+    // (the eight pieces of a window are sixteen plain variables and two macros: arrays or structs handed to lambdas by
+    // reference stayed in scratch memory, 272 bytes of it, and the walk ran 35 % slower than round 2's)
+    static_assert(kWinQuads == 8, "eight pieces per window");
+    auto piece_offset = [&](int i) -> uint32_t {          // uint4 offset of this lane's piece i inside a window's lines
+        const uint32_t w_a = a_first + (uint32_t)((i * 64 + lane) >> 3);
+        return (w_a < n ? w_a : n - 1) * kWinQuads + (uint32_t)(lane & 7);
     };
-    auto to_lds = [&](const uint4 (&buf)[kWinQuads]) {    // each lane writes and reads its own row only: no barrier
-#pragma unroll
-        for (int q = 0; q < kWinQuads; ++q) line_codes[lane][q] = buf[q];
-    };
-    uint4 buf_a[kWinQuads], buf_b[kWinQuads], buf_c[kWinQuads];
-    load_window(wmax, buf_a);
-    load_window(wmax - 1, buf_b);
-    load_window(wmax - 2, buf_c);
+    const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3), o4 = piece_offset(4),
+                   o5 = piece_offset(5), o6 = piece_offset(6), o7 = piece_offset(7);
+    uint4 *my_slot = &line_codes[(lane >> 3) * kLinePitch + (lane & 7)];             // piece i goes 8 walks (rows) further down
+#define SG_LOAD_WINDOW(w, P)                                                                                          \
+    do {                                                                                                              \
+        const uint4 *base_ = all_codes + (size_t)((w) > 0 ? (w) : 0) * n * kWinQuads;   /* below window 0: window 0 again */ \
+        P##0 = base_[o0]; P##1 = base_[o1];                                                                            \
+        if constexpr (kPieces > 2) { P##2 = base_[o2]; P##3 = base_[o3]; }                                            \
+        if constexpr (kPieces > 4) { P##4 = base_[o4]; P##5 = base_[o5]; P##6 = base_[o6]; P##7 = base_[o7]; }        \
+    } while (0)
+#define SG_TO_LDS(P)                                                                                                  \
+    do {                                                                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       /* the walks have read the window that is replaced */ \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        my_slot[0 * 8 * kLinePitch] = P##0; my_slot[1 * 8 * kLinePitch] = P##1;                                        \
+        if constexpr (kPieces > 2) { my_slot[2 * 8 * kLinePitch] = P##2; my_slot[3 * 8 * kLinePitch] = P##3; }        \
+        if constexpr (kPieces > 4) {                                                                                  \
+            my_slot[4 * 8 * kLinePitch] = P##4; my_slot[5 * 8 * kLinePitch] = P##5;                                    \
+            my_slot[6 * 8 * kLinePitch] = P##6; my_slot[7 * 8 * kLinePitch] = P##7;                                    \
+        }                                                                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                         \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
+    } while (0)
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4, wa4 = z4, wa5 = z4, wa6 = z4, wa7 = z4;
+    uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4, wb4 = z4, wb5 = z4, wb6 = z4, wb7 = z4;
+    SG_LOAD_WINDOW(wmax, wa);
+    SG_LOAD_WINDOW(wmax - 1, wb);
     // Band row of a round r = r - (right moves up to and including r) = r - (rights_before + popcount of the block's move
     // bits up to r): no state carried from step to step, and a shorter dependency chain than an LDS lookup.
     // d_blk = move bits of the 32-round block the current window lies in; rights_before = right moves before that block,
@@ -674,29 +717,32 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         if (blk == start_blk) rights_before = (sum.y - sum.w) - __popc(d_blk & ((2u << (sum.y & 31)) - 1u));
     };
     enter_block();
-    to_lds(buf_a);
+    SG_TO_LDS(wa);
+    const uint2 *my_line = reinterpret_cast<const uint2 *>(&line_codes[lane * kLinePitch]);
     auto walk_window = [&](int w) {
-        while (walking && ((y + x) / kWinRounds) == w) {
-            const int r = y + x;
-            const uint2 cw = reinterpret_cast<const uint2 *>(&line_codes[lane][0])[r & (kWinRounds - 1)];
-            const int top = r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
+        unsigned r = (unsigned)(y + x);                   // the round of the walk's cell (never negative)
+        while (walking && (r / kCodeWindow) == (unsigned)w) {
+            const uint2 cw = my_line[r & (kCodeWindow - 1)];
+            const int top = (int)r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
             const int bl = 31 - (y - top);
-            const unsigned code = decode_code(cw, bl, tag_format);                   // never 0 on a live path
-            y -= (code == 1 || code == 2) ? 1 : 0;        // 1 diag, 2 up: one row back
-            x -= (code == 1 || code == 3) ? 1 : 0;        // 1 diag, 3 left: one column back
-            const unsigned sh = 2 * (steps & 15u);
-            if (steps & 16u) acc_hi |= code << sh; else acc_lo |= code << sh;
+            // tag of the cell's predecessor: 3 diagonal, 2 up, 1 left (never 0 on a live path)
+            unsigned tag;
+            if constexpr (PACKED) tag = (unsigned)((((unsigned long long)cw.y << 32) | cw.x) >> (2 * bl)) & 3u;
+            else tag = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
+            y -= (int)(tag >> 1);                         // diagonal, up: one row back
+            x -= (int)(tag & 1u);                         // diagonal, left: one column back
+            r = (unsigned)(y + x);
+            acc |= (unsigned long long)((4u - tag) & 3u) << (2 * (steps & 31u));     // the move: 1 diag, 2 up, 3 left
             ++steps;
             if ((steps & 31u) == 0) {
-                if (real) my_moves[(steps >> 5) - 1] = ((unsigned long long)acc_hi << 32) | acc_lo;
-                acc_lo = acc_hi = 0;
+                if (real) my_moves[(steps >> 5) - 1] = acc;
+                acc = 0;
             }
-            walking = code != 0 && (y | x) != 0;
+            walking = tag != 0 && r != 0;
         }
     };
-    auto leave_window = [&](int w, const uint4 (&below)[kWinQuads]) {         // w > 0: window w - 1 comes next
-        to_lds(below);
-        if ((w & 1) == 0) {                               // window w - 1 lies in the 32-round block below
+    auto next_block = [&](int w) {                        // leaving window w > 0: window w - 1 comes next
+        if ((w & 1) == 0) {                               // ... and lies in the 32-round block below
             --blk;
             d_blk = d_below;
             d_below = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;
@@ -704,62 +750,103 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
             enter_block();
         }
     };
-    // roles at the top of the loop: LDS holds window w, buf_b window w - 1, buf_c window w - 2, buf_a is free
+    // roles at the top of the loop: LDS holds window w, wb window w - 1, wa is free (two windows requested ahead)
     for (int w = wmax;;) {
-        load_window(w - 3, buf_a); walk_window(w); if (w == 0) break; leave_window(w, buf_b); --w;
-        load_window(w - 3, buf_b); walk_window(w); if (w == 0) break; leave_window(w, buf_c); --w;
-        load_window(w - 3, buf_c); walk_window(w); if (w == 0) break; leave_window(w, buf_a); --w;
+        SG_LOAD_WINDOW(w - 2, wa); walk_window(w); if (w == 0) break; SG_TO_LDS(wb); next_block(w); --w;
+        SG_LOAD_WINDOW(w - 2, wb); walk_window(w); if (w == 0) break; SG_TO_LDS(wa); next_block(w); --w;
     }
+#undef SG_LOAD_WINDOW
+#undef SG_TO_LDS
     if (real) {
-        if (steps & 31u) my_moves[steps >> 5] = ((unsigned long long)acc_hi << 32) | acc_lo;
+        if (steps & 31u) my_moves[steps >> 5] = acc;
         scores[a] = sum.x;
         lengths[a] = steps + 1;                           // positions = moves + 1
     }
 }
 
+// The walk's moves are a bit stream, 2 bits per move (1 diag, 2 up, 3 left), move t at bits 2t of the alignment's move words.
+// Position i of the ascending list is the sum of the deltas of moves total-2 .. total-1-i, so a wavefront expands 512
+// positions per trip: lane l takes the EIGHT moves of positions 8l .. 8l+7 of the chunk as one 16-bit field of the stream
+// (y steps = c1 xor c0, x steps = c0 of every 2-bit code: two masks), a 64-lane prefix sum of the lanes' popcounts places the
+// lane, and position k of the lane is the lane's base + popcount of the top k+1 fields -- two v_bcnt with an accumulator per
+// coordinate.  ~0.2 instructions per position (round 2: one position per lane and prefix sum, ~0.75: the kernel was bound by
+// instruction issue, 3.4 TB/s of stores).  The lanes' 64-byte results cross LDS so that every store instruction writes
+// one contiguous, line-aligned kilobyte.
+constexpr int kExpPitch = 5;                              // uint4 per lane row in LDS (4 used): the 80-byte pitch keeps 16-byte accesses conflict-free
+
 __global__ void __launch_bounds__(256)
 sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const uint32_t *__restrict__ lengths,
                  int32_t *__restrict__ tracebacks, uint32_t cap)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint4 stage[4][64 * kExpPitch];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);                  // one wavefront per alignment
-    if (a >= n) return;
-    const unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
+    if (a >= n) return;                                   // wave-uniform; only wave-level synchronisation below
+    const uint32_t *stream = reinterpret_cast<const uint32_t *>(moves + (size_t)a * kMoveWords);
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
     const int total = (int)lengths[a];                    // positions; moves 0 .. total-2 in walking order
     const int limit = total < (int)cap ? total : (int)cap;                    // positions to write
-    // position i = the sum of the deltas of positions 1 .. i; the delta of position i is move total - 1 - i of the walk
-    auto delta = [&](int i) -> unsigned {
-        unsigned d = 0;
-        if (i >= 1 && i < total) {
-            const int t = total - 1 - i;
-            const unsigned code = (unsigned)(my_moves[t >> 5] >> (2 * (t & 31))) & 3u;
-            d = ((code == 1 || code == 2) ? 1u : 0u) | ((code == 1 || code == 3) ? 0x10000u : 0u);
-        }
-        return d;
-    };
-    // every 64-position store starts on a 128-byte line: the first chunk begins `skew` positions before out[0]
+    // every 1 KB store of the wavefront starts on a 128-byte line: the first chunk begins `skew` positions before out[0]
     const int skew = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 15u);
-    unsigned carry = 0;                                   // y | x << 16 of the position before the chunk
-    for (int base = -skew; base < limit; base += 256) {
-        unsigned d[4];
+    uint4 *my_row = &stage[wv][lane * kExpPitch];
+    const uint4 *my_pieces = &stage[wv][(lane >> 2) * kExpPitch + (lane & 3)];            // + j * 16 rows for store j
+    unsigned carry = 0;                                   // y | x << 16 of the last position before the chunk
+    for (int base = -skew; base < limit; base += 512) {
+        const int s = total - 1 - (base + 8 * lane) - 7;  // position base + 8 lane + k takes move s + 7 - k
+        // the 16 bits of the stream that start at move s (s < 0 or past the last move: those fields are masked off below)
+        const int sc = s < 0 ? 0 : s;
+        int dw = (2 * sc) >> 5;
+        dw = dw < 2 * kMoveWords - 2 ? dw : 2 * kMoveWords - 2;              // the 8-byte fetch stays inside the move words
+        const unsigned long long w = stream[dw] | ((unsigned long long)stream[dw + 1] << 32);
+        const int up = -2 * s < 16 ? -2 * s : 16;
+        unsigned f = s >= 0 ? (unsigned)(w >> ((2 * sc) & 31)) : (unsigned)w << up;
+        const int lo = -s < 0 ? 0 : (-s > 8 ? 8 : -s), hi = total - 1 - s < 0 ? 0 : (total - 1 - s > 8 ? 8 : total - 1 - s);
+        f &= ((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u);             // fields lo .. hi-1 hold moves 0 .. total-2
+        const unsigned yb = (f ^ (f >> 1)) & 0x5555u, xb = f & 0x5555u;       // a row step / a column step per move
+        // inclusive prefix sum of the lanes' totals (y in the low half, x in the high half: both stay below 2^15)
+        const unsigned own = (unsigned)__popc(yb) | ((unsigned)__popc(xb) << 16);
+        unsigned v = own;
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
+                       r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+        const int row = lane >> 4;
+        v += carry + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u) - own;   // = the position before this lane's first
+        const unsigned by = v & 0xFFFFu, bx = v >> 16;
+        carry += r0 + r1 + r2 + r3;
+        // position k of the lane = base + the steps of fields 7 .. 7-k
+        auto py = [&](int k) { return (int)(by + (unsigned)__popc(yb & ((0xFFFFu << (2 * (7 - k))) & 0xFFFFu))); };
+        auto px = [&](int k) { return (int)(bx + (unsigned)__popc(xb & ((0xFFFFu << (2 * (7 - k))) & 0xFFFFu))); };
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // (the previous trip's reads of the stage are done)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[c] = delta(base + 64 * c + lane);      // four independent fetches in flight
+        for (int q = 0; q < 4; ++q) my_row[q] = make_uint4((unsigned)py(2 * q), (unsigned)px(2 * q), (unsigned)py(2 * q + 1), (unsigned)px(2 * q + 1));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        if (base >= 0 && base + 512 <= limit) {           // (wave-uniform) a chunk inside the list: four unconditional 1 KB stores
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = base + 64 * c + lane;
-            // inclusive prefix sum over the wavefront (y in the low half, x in the high half: both stay below 2^15)
-            unsigned v = d[c];
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-            v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-            const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
-                           r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-            const int row = lane >> 4;
-            v += carry + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
-            if (i >= 0 && i < limit) out[i] = make_int2((int)(v & 0xFFFFu), (int)(v >> 16));
-            carry += r0 + r1 + r2 + r3;
+            for (int j = 0; j < 4; ++j) {                 // store j: piece g = 64 j + lane = positions base + 2g, base + 2g + 1
+                const uint4 pc = my_pieces[j * 16 * kExpPitch];
+                const v4u both = {pc.x, pc.y, pc.z, pc.w};
+                __builtin_nontemporal_store(both, reinterpret_cast<v4u *>(out + base + 2 * (64 * j + lane)));   // streamed: never read again on the GPU
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 pc = my_pieces[j * 16 * kExpPitch];
+                const int e = base + 2 * (64 * j + lane);
+                if (e >= 0 && e + 1 < limit) {
+                    const v4u both = {pc.x, pc.y, pc.z, pc.w};
+                    __builtin_nontemporal_store(both, reinterpret_cast<v4u *>(out + e));
+                } else {
+                    if (e >= 0 && e < limit) out[e] = make_int2((int)pc.x, (int)pc.y);
+                    if (e + 1 >= 0 && e + 1 < limit) out[e + 1] = make_int2((int)pc.z, (int)pc.w);
+                }
+            }
         }
     }
 }
@@ -768,7 +855,7 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
 
 namespace {
 inline size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
-inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeStride * sizeof(uint2)); }
+inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeWindows * kCodeWindow * sizeof(uint2)); }
 inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * sizeof(uint32_t)); }
 }  // namespace
 
@@ -824,7 +911,9 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
         else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
     }
     if (tb_name && tb_len)
-        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n, tuning) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
+        snprintf(tb_name, tb_len, "%s", !choose_lane_traceback(n, tuning) ? "sg_traceback_kernel"
+                                        : sweep != 0 && sweep < 100 ? "sg_walk_lane_kernel<1> + sg_expand_kernel"
+                                                                    : "sg_walk_lane_kernel<0> + sg_expand_kernel");
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
@@ -875,8 +964,13 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     if (e != hipSuccess) return e;
     const bool lane_tb = choose_lane_traceback(n, tuning);
     if (lane_tb) {
-        hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
-                           summary, moves, d_scores, d_lengths);
+        // the record format follows the sweep: packed tags from the split sweeps, two ballot words from the half-wavefront one
+        if (sweep != 0 && sweep < 100)
+            hipLaunchKernelGGL(sg_walk_lane_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
+                               summary, moves, d_scores, d_lengths);
+        else
+            hipLaunchKernelGGL(sg_walk_lane_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
+                               summary, moves, d_scores, d_lengths);
         hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
                            d_tracebacks, (uint32_t)cap);
     }

@@ -85,7 +85,12 @@ template <int L>
 __device__ __forceinline__ int from_prev_lane(int v, int group_mask)
 {
     if constexpr (L == 64) {
+#ifdef SWMI_AB_SHFL_UP      // A/B build only (make ab_shfl_up, tools/shfl_up_ab.py; never shipped): north_star's literal
+        const int s = __shfl_up(v, 1);                       // __shfl_up(h, 1), which hipcc lowers to ds_bpermute_b32
+        return (threadIdx.x & 63) ? s : 0;
+#else
         return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+#endif
     } else if constexpr (L == 32) {
         return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true) & group_mask;
     } else if constexpr (L == 16) {
@@ -835,15 +840,6 @@ sw128_lut_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ 
 // E and F are kept saturated at 0 (v_sub_u32 clamp): max(0, E) is all H ever needs, and it makes every out-of-band or
 // out-of-matrix neighbour (which the DPP shifts and the pad entries deliver as 0) behave as -infinity.  Cells past the end
 // of either sequence keep computing; their values are bounded by the running maximum (open, ext >= 0), so nothing is masked.
-__device__ __forceinline__ int from_lane_below(int v)   // value of lane m-1, 0 into lane 0
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-}
-__device__ __forceinline__ int from_lane_above(int v)   // value of lane m+1, 0 into lane 63
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-}
-
 // Value of lane m-1 / m+1 minus `ext`, NOT saturated: the DPP shift rides on the subtraction (v_sub*_dpp, one half-rate
 // instruction instead of v_mov_b32_dpp + v_sub_u32 clamp).  An invalid source lane reads 0, so the band's edge lanes get
 // -ext: a negative E / F acts as the "-infinity" the saturated form expressed as 0 (every consumer takes a max with a
@@ -907,49 +903,60 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
     int b_cur = (int)pb[0];
     int best = 0;
 
-    if constexpr (kOpenGeExt) {
-        // open >= ext (the usual case).  With hm = max(H - (open - ext), 0) both gap recurrences become
-        //   E = max(E_left, hm_left) - ext,   F = max(F_up, hm_up) - ext            (floored at 0, or left negative: see below)
-        // (saturating subtraction distributes over max, and (H -sat (open-ext)) -sat ext = H -sat open), so a cell hands
-        // its neighbours ONE value each -- me = max(E, hm) to the right, mf = max(F, hm) downwards -- and one of the two
-        // crosses lanes.  The crossing one is subtracted without saturation by a v_sub_dpp (the lane shift is free on it);
-        // it may come out negative, which is harmless: it only feeds max3(t, f, e) beside a saturated partner (>= 0) and
-        // max(e, hm) beside hm >= 0.  Per cell: dot4 + max3 + sub_dpp + 2 sub + 2 max.
-        const int oe = gap_open - gap_ext;
-        // gfx9 DPP encodings take no SGPR operand: `ext` has to sit in a VGPR for hipcc to fold the lane shift into the
-        // subtraction (v_subrev_u32_dpp); from an SGPR it emits v_mov_b32_dpp + v_subrev_u32 instead
-        const int ext_v = keep(gap_ext);
+    // Both gap recurrences are FOLDED so that a cell hands each neighbour ONE value and only one of the two crosses lanes.
+    //   open >= ext (the usual case): with hm = max(H - (open - ext), 0)
+    //       E = max(E_left, hm_left) - ext,   F = max(F_up, hm_up) - ext
+    //     (saturating subtraction distributes over max, and (H -sat (open-ext)) -sat ext = H -sat open): the cell hands
+    //     me = max(E, hm) to the right and mf = max(F, hm) downwards; per cell dot4 + max3 + sub_dpp + 2 sub + 2 max.
+    //   open < ext (a gap's first position is the cheap one): with em = E - (ext - open), fm = F - (ext - open)
+    //       E = max(em_left, H_left) - open,   F = max(fm_up, H_up) - open
+    //     the cell hands me = max(em, H) and mf = max(fm, H); one more subtraction per cell (round 2 ran this case unfolded:
+    //     two lane-crossing moves, four saturating subtractions, two maxes).
+    // The crossing value is subtracted without saturation by a v_sub_dpp (the lane shift is free on it); it may come out
+    // negative, which is harmless: it only feeds max3(t, f, e) beside a saturated partner (>= 0) and a max beside a value
+    // >= 0 (hm resp. H).  em / fm are plain differences for the same reason.
+    {
+        const int step_cost = kOpenGeExt ? gap_ext : gap_open;           // what the value handed over loses on arrival
+        const int fold = kOpenGeExt ? gap_open - gap_ext : gap_ext - gap_open;
+        // gfx9 DPP encodings take no SGPR operand: the subtrahend has to sit in a VGPR for hipcc to fold the lane shift into
+        // the subtraction (v_subrev_u32_dpp); from an SGPR it emits v_mov_b32_dpp + v_subrev_u32 instead
+        const int cost_v = keep(step_cost);
         int h0 = 0, me0 = 0, mf0 = 0;           // last cell on the even diagonal 2m
         int h1 = 0, me1 = 0, mf1 = 0;           // last cell on the odd diagonal 2m+1
+        auto hand_over = [&](int h, int e, int f, int &me, int &mf) {
+            if constexpr (kOpenGeExt) {
+                int hm = sat_sub<false>(h, fold);
+                BA_NOP(1, hm);
+                me = vmax<kI16>(e, hm);
+                BA_NOP(2, me);
+                mf = vmax<kI16>(f, hm);
+                BA_NOP(3, mf);
+            } else {
+                const int em = e - fold, fm = f - fold;                  // may be negative: they only meet h >= 0 in a max
+                me = vmax<kI16>(em, h);
+                mf = vmax<kI16>(fm, h);
+                BA_NOP(3, mf);
+            }
+        };
         auto pair_of_steps = [&](int b_next) {
             {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
-                const int e = below_minus(me1, ext_v);
-                int f = sat_sub<false>(mf1, gap_ext);
+                const int e = below_minus(me1, cost_v);
+                int f = sat_sub<false>(mf1, step_cost);
                 BA_NOP(0, f);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
                 const int tf = t > f ? t : f;
                 h0 = tf > e ? tf : e;           // v_max3_i32; >= 0 because f >= 0
-                int hm = sat_sub<false>(h0, oe);
-                BA_NOP(1, hm);
-                me0 = vmax<kI16>(e, hm);
-                BA_NOP(2, me0);
-                mf0 = vmax<kI16>(f, hm);
-                BA_NOP(3, mf0);
+                hand_over(h0, e, f, me0, mf0);
             }
             b_cur = b_next;
             {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
-                int e = sat_sub<false>(me0, gap_ext);
+                int e = sat_sub<false>(me0, step_cost);
                 BA_NOP(0, e);
-                const int f = above_minus(mf0, ext_v);
+                const int f = above_minus(mf0, cost_v);
                 const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
                 const int te = t > e ? t : e;
                 h1 = te > f ? te : f;           // >= 0 because e >= 0
-                int hm = sat_sub<false>(h1, oe);
-                BA_NOP(1, hm);
-                me1 = vmax<kI16>(e, hm);
-                BA_NOP(2, me1);
-                mf1 = vmax<kI16>(f, hm);
-                BA_NOP(3, mf1);
+                hand_over(h1, e, f, me1, mf1);
             }
             const int hb = h0 > h1 ? h0 : h1;
             best = best > hb ? best : hb;
@@ -970,40 +977,6 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
             pair_of_steps(b_next);
             a_cur = a_next;
         }
-    } else {
-    int h0 = 0, e0 = 0, f0 = 0;                 // last cell on the even diagonal 2m
-    int h1 = 0, e1 = 0, f1 = 0;                 // last cell on the odd diagonal 2m+1
-
-    for (int u = 0; u < len; ++u) {
-        const int b_next = (int)pb[u + 1];
-        const int a_next = (int)pa[u + 1];
-        // even step: diagonal 2m, cell (i, j)
-        {
-            const int hl = from_lane_below(h1), el = from_lane_below(e1);
-            const int e = max(sat_sub<false>(el, gap_ext), sat_sub<false>(hl, gap_open));
-            const int f = max(sat_sub<false>(f1, gap_ext), sat_sub<false>(h1, gap_open));
-            const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h0, true);
-            const int tf = t > f ? t : f;
-            h0 = tf > e ? tf : e;               // v_max3_i32; >= 0 because e, f >= 0
-            e0 = e;
-            f0 = f;
-        }
-        b_cur = b_next;
-        // odd step: diagonal 2m+1, cell (i, j+1)
-        {
-            const int hu = from_lane_above(h0), fu = from_lane_above(f0);
-            const int e = max(sat_sub<false>(e0, gap_ext), sat_sub<false>(h0, gap_open));
-            const int f = max(sat_sub<false>(fu, gap_ext), sat_sub<false>(hu, gap_open));
-            const int t = __builtin_amdgcn_sdot4(a_cur, b_cur, h1, true);
-            const int tf = t > f ? t : f;
-            h1 = tf > e ? tf : e;
-            e1 = e;
-            f1 = f;
-        }
-        const int hb = h0 > h1 ? h0 : h1;
-        best = best > hb ? best : hb;
-        a_cur = a_next;
-    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1153,7 +1126,8 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
         if (i16) hipLaunchKernelGGL((sw_banded_affine_kernel<true, true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
         else     hipLaunchKernelGGL((sw_banded_affine_kernel<true, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
     } else {
-        hipLaunchKernelGGL((sw_banded_affine_kernel<false, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+        if (i16) hipLaunchKernelGGL((sw_banded_affine_kernel<false, true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
+        else     hipLaunchKernelGGL((sw_banded_affine_kernel<false, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
     }
     return hipGetLastError();
 }

@@ -26,7 +26,12 @@ bool g_knobs_read = false;
 // Schedule setting, process-wide: lanes in the low half, flags in the high half, ONE atomic so that a launch that races
 // with swmi_set_schedule sees either the old pair or the new one, never a mix.
 std::atomic<uint64_t> g_schedule{0};
+// Mapping override of the semi-global kernels (swmi_semiglobal_set_mapping; SWMI_SG_SWEEP / SWMI_SG_TRACEBACK give the initial
+// value at swmi_init): ONE atomic word, sweep in the low half, traceback in the high half, each + 1 so that 0 = automatic.
+std::atomic<uint64_t> g_sg_mapping{0};
 }  // namespace
+
+std::atomic<uint64_t> &sg_mapping_word() { return g_sg_mapping; }
 
 int fail(int code, const char *fmt, ...)
 {
@@ -449,6 +454,7 @@ int init_list(const int *devices, int n)
     (void)hipSetDevice(devices[0]);
     g_ctxs = std::move(fresh);
     if (knobs().lanes && swmi::schedule_supported(knobs().lanes)) g_schedule.store(uint64_t(knobs().lanes));
+    sg_mapping_word().store(uint64_t(uint32_t(knobs().sg_sweep + 1)) | (uint64_t(uint32_t(knobs().sg_traceback + 1)) << 32));
     return SWMI_OK;
 }
 
@@ -716,9 +722,10 @@ int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq
 
 static swmi::SgTuning sg_tuning()
 {
+    const uint64_t m = sg_mapping_word().load(std::memory_order_relaxed);
     swmi::SgTuning t;
-    t.force_sweep = knobs().sg_sweep;
-    t.force_traceback = knobs().sg_traceback;
+    t.force_sweep = int(m & 0xffffffffu) - 1;
+    t.force_traceback = int(m >> 32) - 1;
     return t;
 }
 
@@ -835,6 +842,17 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
                                  size_t cap, void *d_lengths, void *stream)
 {
     return semiglobal_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, nullptr);
+}
+
+int swmi_semiglobal_set_mapping(int sweep, int traceback)
+{
+    const bool sweep_ok = sweep == -1 || sweep == 0 || sweep == 2 || sweep == 4 || (sweep >= 21 && sweep <= 24) ||
+                          (sweep >= 41 && sweep <= 44) || (sweep >= 101 && sweep <= 103);
+    if (!sweep_ok || traceback < -1 || traceback > 1)
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 0, 2, 4, 21..24, 41..44 or 101..103, traceback -1, 0 or 1",
+                    sweep, traceback);
+    sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)) | (uint64_t(uint32_t(traceback + 1)) << 32));
+    return SWMI_OK;
 }
 
 int swmi_semiglobal_release_workspaces(void)

@@ -100,6 +100,7 @@ int check_alive(const Context &ctx);    // SWMI_OK, or SWMI_ERR_NOT_INITIALIZED 
 int num_contexts();
 std::mutex &init_mutex();
 
+std::atomic<uint64_t> &sg_mapping_word();          // semi-global mapping override (swmi_semiglobal_set_mapping)
 int check_params(const int8_t *sm, int gap);
 SmRows pack_rows(const int8_t *sm, int add);
 LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *rows, size_t n);

@@ -33,6 +33,102 @@ def test_rccl_gather_with_one_rank(gpu, oracle):
     sb.close()
 
 
+def test_rccl_ragged_gather_path_with_one_rank(gpu, oracle):
+    """The grouped-ncclBroadcast path ragged shards take (swmi_multi.cpp score_once), rehearsed with the one rank a one-GPU
+    box offers: SWMI_TEST_GATHER_PIECE makes every batch take it and cuts the shard into pieces, so that several
+    broadcasts with different offsets run inside one group (with G = 1 and whole-shard broadcasts the path would be
+    a single call; with equal shards it is never taken at all)."""
+    import os
+    n = 65536 + 17
+    sm = match_matrix(10, -30)
+    a, b = oracle.generate(n, 31, 7)
+    want = oracle.batch(a, b, sm, 15)
+    gpu.shutdown()
+    os.environ["SWMI_TEST_GATHER_PIECE"] = "10000"           # knobs are read at swmi_init
+    try:
+        gpu.init(0)
+        sb = gpu.ShardedBatch(n)
+        sb.generate(31, 7)
+        sb.score(sm, 15, gpu.GATHER_ALL)
+        sb.wait()
+        assert sb.gather_backend() == "rccl" and sb.gather_note() == ""
+        assert np.array_equal(sb.gathered(0), want)
+        r = sb.time(sm, 15, gpu.GATHER_ALL, iters=3)          # the timing helper drives the same path
+        assert r["wall_ms"] > 0 and np.array_equal(sb.gathered(0), want)
+        sb.close()
+    finally:
+        del os.environ["SWMI_TEST_GATHER_PIECE"]
+        gpu.shutdown()
+        gpu.init(0)
+        gpu.set_schedule(0, 0)
+
+
+def test_rccl_that_cannot_be_loaded_is_reported_and_peer_copies_take_over(gpu, oracle):
+    """SWMI_RCCL_LIB names a file that does not exist: SWMI_GATHER_ALL must still deliver the right vector (peer copies), say
+    so through swmi_sharded_gather_backend / _note and leave the reason in swmi_last_error().  A child process: the library
+    decides once per process which librccl it uses, and this one has loaded the real one already."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch, swmi
+swmi.init(0)
+n = 30001
+sb = swmi.ShardedBatch(n)
+sb.generate(5, 0)
+sm = swmi.match_matrix(10, -30)
+sb.score(sm, 15, swmi.GATHER_ALL)
+print("last_error:", swmi.last_error())
+sb.wait()
+print("backend:", sb.gather_backend())
+print("note:", sb.gather_note())
+g = sb.gathered(0)
+np.save(sys.argv[1], g)
+sb.close()
+swmi.shutdown()
+""" % PKG
+    out_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), "swmi_p2p_fallback_%d.npy" % os.getpid())
+    run = subprocess.run([sys.executable, "-c", code, out_file], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=dict(os.environ, SWMI_RCCL_LIB="/nonexistent/librccl-not-here.so"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "backend: p2p" in run.stdout
+    assert "librccl-not-here" in run.stdout.split("note:")[1]
+    assert "peer copies" in run.stdout.split("last_error:")[1].splitlines()[0]
+    a, b = oracle.generate(30001, 5, 0)
+    assert np.array_equal(np.load(out_file), oracle.batch(a, b, match_matrix(10, -30), 15))
+    os.remove(out_file)
+
+
+def test_handles_outlive_shutdown(gpu, oracle):
+    """A queue and a sharded batch created before swmi_shutdown(): every later call on them fails with
+    SWMI_ERR_NOT_INITIALIZED (also after a new swmi_init), and closing them still works -- a garbage-collected binding
+    cannot promise to destroy handles first."""
+    sm = match_matrix(10, -30)
+    a, b = oracle.generate(100, 3, 0)
+    q = gpu.Queue(100, sm, 15)
+    q.submit(a[0], b[0])
+    sb = gpu.ShardedBatch(1000)
+    sb.generate(1, 0)
+    sb.score(sm, 15, gpu.GATHER_NONE)
+    sb.wait()
+    gpu.shutdown()
+    gpu.init(0)                                   # new contexts: the old handles must not attach to them
+    try:
+        for call in (lambda: q.wait(), lambda: q.reset(), lambda: sb.score(sm, 15, gpu.GATHER_NONE),
+                     lambda: sb.wait(), lambda: sb.scores(), lambda: sb.generate(1, 0)):
+            with pytest.raises(gpu.SwmiError) as e:
+                call()
+            assert e.value.code == gpu.ERR_NOT_INITIALIZED
+        q.close()
+        sb.close()
+        assert np.array_equal(gpu.score_batch(a, b, sm, 15), oracle.batch(a, b, sm, 15))     # the new contexts work
+    finally:
+        gpu.set_schedule(0, 0)
+
+
 def test_two_threads_through_the_c_abi(gpu, oracle):
     """Concurrent callers: two threads score host batches and device batches on their own streams while a third keeps
     changing the schedule -- every result must equal the oracle (the schedule only changes HOW, never WHAT)."""
@@ -167,6 +263,21 @@ def test_resident_shards_all_gather_modes(two, oracle, n, gather):
     assert np.array_equal(sb.scores(), want)
     for index in range(2 if gather == two.GATHER_ALL else 1 if gather == two.GATHER_ROOT else 0):
         assert np.array_equal(sb.gathered(index), want), "gathered vector on GPU index %d" % index
+    sb.close()
+
+
+def test_a_gpu_bound_twice_gathers_over_peer_copies_and_says_why(two, oracle):
+    n = 50000
+    sb = two.ShardedBatch(n)
+    sb.generate(8, 0)
+    assert sb.gather_backend() == "undecided"
+    sb.score(match_matrix(10, -30), 15, two.GATHER_ALL)
+    assert "peer copies" in two.last_error() and "bound twice" in two.last_error()
+    sb.wait()
+    assert sb.gather_backend() == "p2p" and "bound twice" in sb.gather_note()
+    a, b = oracle.generate(n, 8, 0)
+    want = oracle.batch(a, b, match_matrix(10, -30), 15)
+    assert np.array_equal(sb.gathered(0), want) and np.array_equal(sb.gathered(1), want)
     sb.close()
 
 

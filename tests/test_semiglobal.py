@@ -29,13 +29,11 @@ def test_oracle_reproduces_the_reference_results(oracle, golden):
 
 
 @pytest.fixture
-def sg_kernels(monkeypatch):
+def sg_kernels(swmi_mod):
     """Select the sweep mapping (0 = band per half-wavefront, 4 / 2 = band split over 4 / 2 lanes) and the traceback
-    mapping (0 = wavefront per walk, 1 = lane per walk); by default the batch size decides.  The library reads the variables at every launch."""
-    def choose(sweep, traceback):
-        monkeypatch.setenv("SWMI_SG_SWEEP", str(sweep))
-        monkeypatch.setenv("SWMI_SG_TRACEBACK", str(traceback))
-    return choose
+    mapping (0 = wavefront per walk, 1 = lane per walk) through swmi_semiglobal_set_mapping; by default the batch size decides."""
+    yield swmi_mod.semiglobal_set_mapping
+    swmi_mod.semiglobal_set_mapping(-1, -1)
 
 
 @pytest.mark.gpu

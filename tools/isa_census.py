@@ -108,7 +108,7 @@ def disassemble(lib_path=DEFAULT_LIB):
 
 KERNEL_NAMES = ("sw128_lut_kernel", "sw128_pk_kernel", "sw128_kernel", "sw_banded_affine_kernel", "sw_banded_affine_tile_kernel",
                 "sg_forward_split_kernel", "sg_forward_kernel", "sg_traceback_kernel", "sg_walk_lane_kernel", "sg_expand_kernel",
-                "sg_pack_streams_kernel", "generate_kernel", "unpack_kernel")
+                "sg_pack_streams_kernel", "pk_max3_selftest_kernel", "generate_kernel", "unpack_kernel")
 
 
 def readable(symbol):
@@ -120,7 +120,7 @@ def readable(symbol):
                 return name
             args = re.findall(r"L[a-z](\d+)E", m.group(2))
             if name == "sw128_pk_kernel" and len(args) == 3 and args[2] == "4":
-                args = args[:2]             # <MODE, BIAS, L>: the L = 4 instantiation keeps its two-argument name
+                args = args[:2]             # <MODE, VARIANT, L>: the L = 4 instantiation keeps its two-argument name
             return "%s<%s>" % (name, ",".join(args))
     return symbol
 

@@ -30,10 +30,7 @@ for n in sizes:
     for sweep, trace in variants:
         if (sweep == 0 or trace == 0) and n > 65536:
             continue
-        if sweep < 0:
-            os.environ.pop("SWMI_SG_SWEEP", None); os.environ.pop("SWMI_SG_TRACEBACK", None)
-        else:
-            os.environ["SWMI_SG_SWEEP"], os.environ["SWMI_SG_TRACEBACK"] = str(sweep), str(trace)
+        swmi.semiglobal_set_mapping(sweep if sweep >= 0 else -1, trace if sweep >= 0 else -1)
         swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         a, b = swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         chk = (int(scores.sum().item()), int(lengths.sum().item()), int(tb[:: max(1, n // 64), :4096].sum().item()))
