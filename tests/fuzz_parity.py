@@ -33,11 +33,15 @@ t_end = time.time() + args.seconds
 total = mism = rounds = 0
 while time.time() < t_end:
     seed = int(rng.integers(0, 2**62)); first = int(rng.integers(0, 2**40))
-    kind = rounds % 4
+    kind = rounds % 5
     if kind == 0: sm = swmi.match_matrix(10, -30); gap = 15
     elif kind == 1: sm = swmi.match_matrix(1, -1); gap = 1
     elif kind == 2: sm = rng.integers(-128, 128, 16).astype(np.int8); gap = int(rng.integers(0, 128))
-    else: sm = rng.integers(-12, 13, 16).astype(np.int8); gap = int(rng.integers(0, 9))
+    elif kind == 3: sm = rng.integers(-12, 13, 16).astype(np.int8); gap = int(rng.integers(0, 9))
+    else:                    # every score + 2 gap in [0, 255], some score + gap < 0: the packed kernel's vertical-offset cell
+        gap = int(rng.integers(1, 61))
+        sm = rng.integers(-2 * gap, min(127, 255 - 2 * gap) + 1, 16).astype(np.int8)
+        sm[int(rng.integers(0, 16))] = -2 * gap
     L = [4, 4, 8, 4, 16, 2, 4, 32, 64][rounds % 9]      # L = 4 (the packed kernel unless a flag says otherwise) meets every parameter family
     swmi.set_schedule(L, int((0, 0, 1, 8)[int(rng.integers(0, 4))]))
     swmi.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, seed, first, st)

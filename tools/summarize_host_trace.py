@@ -11,13 +11,12 @@ ev = [("K", int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]
 ev += [("H2D" if "HOST_TO_DEVICE" in r["Direction"].upper() or "H2D" in r["Direction"].upper() else "D2H", int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
         "%d B" % int(r.get("Bytes", r.get("Size", 0)) or 0)) for r in m]
 ev.sort(key=lambda e: e[1])
-# split into calls: a gap of more than 1 ms between consecutive events starts a new call
+# split into calls: a call ends with the device-to-host copy of its scores
 calls, cur = [], []
 for e in ev:
-    if cur and e[1] - max(x[2] for x in cur) > 1_000_000:
-        calls.append(cur); cur = []
     cur.append(e)
-if cur: calls.append(cur)
+    if e[0] == "D2H":
+        calls.append(cur); cur = []
 def describe(call):
     t0 = call[0][1]
     h2d = [(s, e) for kind, s, e, _ in call if kind == "H2D"]
@@ -27,11 +26,16 @@ def describe(call):
         for hs, he in h2d:
             under += max(0, min(ke, he) - max(ks, hs))
     tot_k = sum(e - s for s, e in kern)
-    print("call: %d H2D copies %.3f ms, %d kernels %.3f ms, span %.3f ms; kernel time under an H2D copy: %.3f ms (%.0f %%)" % (
+    print("call: %d H2D copy commands %.3f ms busy, %d kernels %.3f ms, first copy to end of the score copy %.3f ms; "
+          "kernel time under an H2D copy: %.3f ms (%.0f %%); exposed kernel time %.3f ms" % (
         len(h2d), sum(e - s for s, e in h2d) / 1e6, len(kern), tot_k / 1e6, (max(x[2] for x in call) - t0) / 1e6, under / 1e6,
-        100.0 * under / tot_k if tot_k else 0))
+        100.0 * under / tot_k if tot_k else 0, (tot_k - under) / 1e6))
     for kind, s, e, what in call:
-        print("   %-4s %9.3f .. %9.3f ms  %s" % (kind, (s - t0) / 1e6, (e - t0) / 1e6, what))
-big = [c for c in calls if sum(1 for x in c if x[0] == "H2D") >= 2]
-for c in (big[2:3] + big[-1:]) if len(big) >= 4 else big[-2:]:
-    describe(c)
+        print("   %-4s %9.3f .. %9.3f ms  %s" % (kind, (s - t0) / 1e6, (e - t0) / 1e6, what if kind == "K" else ""))
+by_kernels = {}
+for c in calls:
+    nk = sum(1 for x in c if x[0] == "K")
+    if nk:
+        by_kernels[nk] = c                     # the last call of each shape (4 granules = 1M pairs, 7 = 4M pairs)
+for nk in sorted(by_kernels):
+    describe(by_kernels[nk])

@@ -33,7 +33,7 @@ try:
     import isa_census
     for k in list(out):
         m = re.match(r"(\w+)(<([^>]*)>)?", k)
-        readable = m.group(1) + ("<%s>" % ",".join(v.strip() for v in m.group(3).split(",")) if m.group(3) else "")
+        readable = m.group(1) + ("<%s>" % ",".join({"true": "1", "false": "0"}.get(v.strip(), v.strip()) for v in m.group(3).split(",")) if m.group(3) else "")
         c = isa_census.census_for("^" + re.escape(readable) + "$")
         if readable in c:
             hashes[k] = c[readable]["code_sha256"]
