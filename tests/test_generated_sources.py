@@ -14,6 +14,8 @@ def test_packed_kernel_sweeps_are_what_their_generator_prints():
 
 def test_cell_microbenchmark_is_what_its_generator_prints():
     mb = os.path.join(ROOT, "tools", "microbench")
-    for gen, src in (("gen_cell_v3.py", "cell_v3.hip"), ("gen_cell_order.py", "cell_order.hip")):
-        out = subprocess.run([sys.executable, os.path.join(mb, gen)], stdout=subprocess.PIPE, text=True, check=True, cwd=mb).stdout
+    for gen, src in (("gen_cell_v3.py", "cell_v3.hip"), ("gen_cell_order.py", "cell_order.hip"), ("gen_valu_mix.py mix", "valu_mix.hip"),
+                     ("gen_valu_mix.py nop", "valu_mix_nop.hip")):
+        out = subprocess.run([sys.executable] + [os.path.join(mb, gen.split()[0])] + gen.split()[1:], stdout=subprocess.PIPE, text=True,
+                             check=True, cwd=mb).stdout
         assert out == open(os.path.join(mb, src)).read(), "%s is stale: python3 %s > %s" % (src, gen, src)
