@@ -21,7 +21,7 @@ Sections (selected with PK_SECTION = 100 * variant + rows per lane before includ
                     Lanes hand each other H itself (exact), so row 0 adds D_0 to what it takes as `up` (one add per step).
                     Per two rows: 2 v_perm, 2 max3, 2 sat-sub, 2 paired adds, 1 max3 (best) = 9 instructions (round 2's
                     bias form: 11).  Pad columns look up 0, i.e. act as score -2 gap: harmless (kernel header).
-The code expects, in the including scope: `col` (per-column table offsets), `tables(code, cx, cy)`, `rsel[R]`, `group_mask`,
+The code expects, in the including scope: `col` (per-column table offsets), `tables_at(t, cx, cy)`, `rsel[R]`, `group_mask`,
 `gap` (int), `L` (lanes per pair of alignments) and defines `pk_best` (packed running best) for the epilogue.
 
 Run: python3 gen_pk_sweeps.py > pk_sweeps_gen.inc   (the Makefile does; tests/test_generated_sources.py checks the committed
@@ -134,16 +134,15 @@ def section(variant, R):
         o.append("    const uint32_t pk_g2 = (uint32_t)gap | ((uint32_t)gap << 16);")
     o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0, pk_up0 = 0;")
     o.append("    uint32_t pk_u0 = 0, pk_u1 = 0;          // H(last row of the lane before): this step's column / the previous one, alternating")
-    o.append("    uint32_t pk_c1 = col[1], pk_x0, pk_y0;")
-    o.append("    tables(col[0], pk_x0, pk_y0);")
+    o.append("    uint32_t pk_x0, pk_y0;")
+    o.append("    tables_at(0, pk_x0, pk_y0);")
     o.append("    for (int t2 = 0; t2 < T2; ++t2) {")
-    o.append("        const uint32_t pk_c2 = col[2 * t2 + 2], pk_c3 = col[2 * t2 + 3];")
     o.append("        uint32_t pk_x1, pk_y1, pk_x2, pk_y2;")
-    o.append("        tables(pk_c1, pk_x1, pk_y1);")
+    o.append("        tables_at(2 * t2 + 1, pk_x1, pk_y1);")
     o += ["    " + l for l in step(variant, R, "pk_x0", "pk_y0", "pk_u0", "pk_u1", "pk_u1")]
-    o.append("        tables(pk_c2, pk_x2, pk_y2);")
+    o.append("        tables_at(2 * t2 + 2, pk_x2, pk_y2);")
     o += ["    " + l for l in step(variant, R, "pk_x1", "pk_y1", "pk_u1", "pk_u0", "pk_u0")]
-    o.append("        pk_x0 = pk_x2; pk_y0 = pk_y2; pk_c1 = pk_c3;")
+    o.append("        pk_x0 = pk_x2; pk_y0 = pk_y2;")
     o.append("    }")
     o.append("    {   // step 128 + L - 2, the last lane's last column")
     o.append("        uint32_t pk_last;")

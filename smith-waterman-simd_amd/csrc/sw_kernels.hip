@@ -548,18 +548,23 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
         prof[k] = kPadCode;
         prof[PAD + kSeqLen + k] = kPadCode;
     }
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const uint32_t cx = (bx[i / 4] >> (8 * (i % 4))) & 3u, cy = (by[i / 4] >> (8 * (i % 4))) & 3u;
-        prof[PAD + j * R + i] = (cx * 4u) | (cy * 4u) << 16;
-    }
-    // v_perm selector of row i: byte 0 <- byte (base of X's row) of X's column table, byte 2 <- byte (base of Y's row) of
-    // Y's column table (source bytes 4..7), bytes 1 and 3 <- 0x00 (selector 0x0C)
+    // Column codes and row selectors, four at a time: the bases of four rows / columns sit in the four bytes of a dword, so
+    // one mask (and one shift / or) per DWORD prepares all four, and one v_perm_b32 per entry then puts X's byte into byte 0
+    // and Y's byte into byte 2 (round 2 extracted, shifted and merged every entry on its own: ~5 instructions each).
+    //   column code  = (4 * base of X's column) | (4 * base of Y's column) << 16   (byte offsets into lds_tab)
+    //   row selector = byte 0 <- byte (base of X's row) of X's column table, byte 2 <- byte (base of Y's row) of Y's column
+    //                  table (source bytes 4..7), bytes 1 and 3 <- 0x00 (selector 0x0C):  ra | (4 + rb) << 16 | 0x0C000C00
     uint32_t rsel[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const uint32_t ra = (ax[i / 4] >> (8 * (i % 4))) & 3u, rb = (ay[i / 4] >> (8 * (i % 4))) & 3u;
-        rsel[i] = ra | 0x0C040C00u | (rb << 16);
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t cx4 = (bx[w] & 0x03030303u) << 2, cy4 = (by[w] & 0x03030303u) << 2;
+        const uint32_t ra4 = ax[w] & 0x03030303u, rb4 = (ay[w] & 0x03030303u) | 0x04040404u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t pick = (uint32_t)k | 0x0C000C00u | ((uint32_t)(4 + k) << 16);     // byte k of the first, byte k of the second
+            prof[PAD + j * R + 4 * w + k] = __builtin_amdgcn_perm(cy4, cx4, pick);
+            rsel[4 * w + k] = __builtin_amdgcn_perm(rb4, ra4, pick) | 0x0C000C00u;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -582,6 +587,12 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     auto tables = [&](uint32_t code, uint32_t &cx, uint32_t &cy) {
         cx = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code & 0xFFFFu));
         cy = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + (code >> 16));
+    };
+    // the same for column t, with the two halves of the code fetched as two 16-bit LDS reads: no VALU work per step
+    auto tables_at = [&](int t, uint32_t &cx, uint32_t &cy) {
+        const uint16_t *half = reinterpret_cast<const uint16_t *>(col + t);
+        cx = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + half[0]);
+        cy = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + half[1]);
     };
 
     if constexpr (kGenerated) {

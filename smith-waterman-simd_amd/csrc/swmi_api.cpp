@@ -544,6 +544,7 @@ int swmi_use_gpu(int index)
 
 int swmi_shutdown(void)
 {
+    stop_workers();                     // before the contexts go: a worker holds its context's device current
     std::lock_guard<std::mutex> lock(g_init_mu);
     for (auto &c : g_ctxs) {
         destroy_context(*c);

@@ -96,6 +96,7 @@ int last_status();                      // the code the last fail() on this thre
 Context *current();                     // the calling thread's context, made current on its device; nullptr + last_status()
 Context *context_at(int index);         // nullptr if out of range
 std::shared_ptr<Context> context_ref(int index);   // what a handle keeps
+void stop_workers();                    // swmi_multi.cpp: joins the per-GPU host threads of the *_multi entry points (swmi_shutdown)
 int check_alive(const Context &ctx);    // SWMI_OK, or SWMI_ERR_NOT_INITIALIZED when swmi_shutdown() ran after the handle was made
 int num_contexts();
 std::mutex &init_mutex();

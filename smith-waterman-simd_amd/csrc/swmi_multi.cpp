@@ -14,8 +14,10 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 
@@ -84,6 +86,54 @@ void shard_bounds(size_t n, int g, int G, size_t *lo, size_t *hi)
     *hi = l + base + (size_t(g) < extra ? 1 : 0);
 }
 
+// One PERSISTENT host thread per bound GPU for the host-array entry points: a thread's first HIP call costs ~1 ms of runtime
+// set-up, which a thread spawned per call would pay every time (round 2 did: 6.1 ms for a 1M-pair call that takes 4.7 ms on the
+// calling thread) -- and with eight GPUs a shard's whole copy is shorter than that.  Created on first use, joined by
+// swmi_shutdown (stop_workers).
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, stop = false;
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            cv.wait(l, [this] { return has_job || stop; });
+            if (stop) return;
+            l.unlock();
+            job();
+            l.lock();
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> l(mu);
+        job = std::move(f);
+        has_job = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [this] { return !has_job; });
+    }
+};
+std::vector<std::unique_ptr<Worker>> g_workers;
+std::mutex g_workers_mu;                // one multi-GPU host batch at a time (they would serialise on the contexts anyway)
+
+void ensure_workers(int G)
+{
+    while ((int)g_workers.size() < G) {
+        g_workers.emplace_back(new Worker);
+        Worker *w = g_workers.back().get();
+        w->th = std::thread([w] { w->loop(); });
+    }
+}
+
 int multi_host(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out, bool packed)
 {
     int rc = check_params(sm, gap);
@@ -95,31 +145,62 @@ int multi_host(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm,
     const size_t stride = packed ? SWMI_PACKED_LEN : kSeq;
     std::vector<int> rcs(G, SWMI_OK);
     std::vector<std::string> errs(G);
-    std::vector<std::thread> threads;
-    for (int g = 0; g < G; ++g) {
+    std::lock_guard<std::mutex> pool_lock(g_workers_mu);
+    ensure_workers(G);
+    auto shard_job = [&, stride](int g, size_t lo, size_t hi) {
+        const std::shared_ptr<Context> keep = context_ref(g);      // (a racing swmi_shutdown is the caller's bug, but it must not free this)
+        if (!keep) {
+            rcs[g] = SWMI_ERR_NOT_INITIALIZED;
+            errs[g] = "the context disappeared";
+            return;
+        }
+        Context *ctx = keep.get();
+        const hipError_t e = hipSetDevice(ctx->device);          // per host thread, like every HIP "current device"
+        if (e != hipSuccess) {
+            rcs[g] = SWMI_ERR_HIP;
+            errs[g] = std::string("hipSetDevice failed: ") + hipGetErrorString(e);
+            return;
+        }
+        rcs[g] = score_host_batch(*ctx, s1 + lo * stride, s2 + lo * stride, hi - lo, sm, gap, out + lo, packed, false);
+        if (rcs[g] != SWMI_OK) errs[g] = swmi_last_error();      // thread-local text: carry it to the caller's thread
+    };
+    // shard 0 runs on the calling thread (one GPU: no hand-over at all), the others on their GPU's worker
+    std::vector<int> busy;
+    size_t lo0 = 0, hi0 = 0;
+    shard_bounds(n, 0, G, &lo0, &hi0);
+    for (int g = 1; g < G; ++g) {
         size_t lo, hi;
         shard_bounds(n, g, G, &lo, &hi);
         if (hi == lo) continue;
-        threads.emplace_back([=, &rcs, &errs] {
-            const std::shared_ptr<Context> keep = context_ref(g);      // (a racing swmi_shutdown is the caller's bug, but it must not free this)
-            Context *ctx = keep.get();
-            const hipError_t e = hipSetDevice(ctx->device);      // per host thread, like every HIP "current device"
-            if (e != hipSuccess) {
-                rcs[g] = SWMI_ERR_HIP;
-                errs[g] = std::string("hipSetDevice failed: ") + hipGetErrorString(e);
-                return;
-            }
-            rcs[g] = score_host_batch(*ctx, s1 + lo * stride, s2 + lo * stride, hi - lo, sm, gap, out + lo, packed, false);
-            if (rcs[g] != SWMI_OK) errs[g] = swmi_last_error();  // thread-local text: carry it to the caller's thread
-        });
+        g_workers[g]->submit([=, &shard_job] { shard_job(g, lo, hi); });
+        busy.push_back(g);
     }
-    for (auto &t : threads) t.join();
+    if (hi0 > lo0) shard_job(0, lo0, hi0);
+    for (int g : busy) g_workers[g]->wait();
     for (int g = 0; g < G; ++g)
         if (rcs[g] != SWMI_OK) return fail(rcs[g], "GPU index %d: %s", g, errs[g].c_str());
     return SWMI_OK;
 }
 
 }  // namespace
+
+namespace swmi {
+namespace host {
+void stop_workers()
+{
+    std::lock_guard<std::mutex> pool_lock(g_workers_mu);
+    for (auto &w : g_workers) {
+        {
+            std::lock_guard<std::mutex> l(w->mu);
+            w->stop = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    g_workers.clear();
+}
+}  // namespace host
+}  // namespace swmi
 
 struct swmi_sharded_batch {
     size_t n = 0;
