@@ -281,10 +281,11 @@ SWMI_API int swmi_queue_destroy(swmi_queue *q);
  * flags (all give identical scores): bit 0 = never fold the gap into the matrix rows (general cell body);
  * bit 1 = 16-bit-max cell body; bit 2 = LDS score-lookup kernel (L in 16, 8, 4 and foldable parameters only);
  * bit 3 = never the packed kernel.  (Without it, L = 4, 8 and 16 -- what the automatic choice resolves to from 5121 pairs
- * up -- run sw128_pk_kernel: two alignments per register and L lanes per PAIR of alignments, i.e. 32 / 16 / 8 alignments per
- * wavefront, 16-bit cells, v_pk_maximum3_f16 as a packed integer max; ~1.3x
- * the int32 kernel in general and ~1.5x when every score_matrix entry + gap_penalty is >= 0, e.g. the (1,-1,1) parameters
- * of the reference's SmithWaterman_8bit111simd, source.cpp:1105-1225.  DESIGN.md section 5.) */
+ * up -- run sw128_pk_kernel<MODE, VARIANT, L>: two alignments per register and L lanes per PAIR of alignments, i.e. 32 / 16 / 8
+ * alignments per wavefront, 16-bit cells, v_pk_maximum3_f16 as a packed integer max.  VARIANT is the cell body, chosen from
+ * the parameters: 0 when every score_matrix entry + gap_penalty is >= 0 (e.g. (1,-1,1), the parameters of the reference's
+ * SmithWaterman_8bit111simd, source.cpp:1105-1225: ~1.55x the int32 kernel), 2 when every entry + 2 * gap_penalty lies in
+ * [0, 255] (e.g. the harness's (10,-30,15): ~1.4x), 1 otherwise (~1.3x).  DESIGN.md section 5a.) */
 SWMI_API int swmi_set_schedule(int lanes_per_alignment, unsigned flags);
 SWMI_API int swmi_get_schedule(int *lanes_per_alignment, unsigned *flags);
 /* Lanes per alignment a launch of n pairs runs with under the current setting (what 0 = automatic resolves to). */

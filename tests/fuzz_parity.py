@@ -72,7 +72,7 @@ while time.time() < t_end:
         print("MISMATCH seed %d first %d L %d gap %d sm %s: pair %d got %d want %d (%d bad)" % (seed, first, L, gap, sm.tolist(), i, got[i], want[i], bad), flush=True)
     if rounds % 10 == 0:
         print("... %d rounds, %.0f M pairs, %d mismatches" % (rounds, total / 1e6, mism), flush=True)
-print("SW128 fuzz: %d rounds, %d pairs, %d mismatches (all six schedules, folded and general cell, four parameter families, pairs / packed / one-vs-many entries)" % (rounds, total, mism), flush=True)
+print("SW128 fuzz: %d rounds, %d pairs, %d mismatches (all six schedules, folded and general cell, five parameter families, pairs / packed / one-vs-many entries)" % (rounds, total, mism), flush=True)
 
 # ---- semi-global aligner against the real reference (if present) or the oracle --------------------------------------
 ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
