@@ -96,6 +96,16 @@ struct Worker {
     std::condition_variable cv;
     std::function<void()> job;
     bool has_job = false, stop = false;
+    ~Worker() { shut(); }               // also at process exit without swmi_shutdown(): a joinable std::thread must not be destroyed
+    void shut()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
     void loop()
     {
         std::unique_lock<std::mutex> l(mu);
@@ -189,14 +199,7 @@ namespace host {
 void stop_workers()
 {
     std::lock_guard<std::mutex> pool_lock(g_workers_mu);
-    for (auto &w : g_workers) {
-        {
-            std::lock_guard<std::mutex> l(w->mu);
-            w->stop = true;
-            w->cv.notify_all();
-        }
-        if (w->th.joinable()) w->th.join();
-    }
+    for (auto &w : g_workers) w->shut();
     g_workers.clear();
 }
 }  // namespace host
