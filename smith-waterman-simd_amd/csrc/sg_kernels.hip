@@ -94,6 +94,11 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 // masks, and every cross-lane step is a DPP move or a v_readlane (an LDS-crossbar shuffle costs more than all of a
 // round's arithmetic).  ~95 instructions per round (round 1's formulation: ~128).
 constexpr int kScale = 128;
+// PK form of the split sweep: values are stored as  true + round - base  (a gap or a mismatch step then adds 0 / 1 and a
+// match 3: nothing negative is ever added to an unsigned half), re-based every 16 rounds so that the X-drop threshold is
+// kPkFloor again; kPkBase0 = the base before round 1 (threshold 1 + 1 - base = kPkFloor).
+constexpr int kPkFloor = 8;
+constexpr int kPkBase0 = 2 - kPkFloor;
 
 template <int W>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
@@ -237,6 +242,35 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
     streams[t] = out;
 }
 
+// ---- packed 16-bit helpers for the PK form of the split sweep ---------------------------------------------------
+// Two band cells per register.  Every half is an integer in [0, 0x7C00): as bit patterns those are the non-negative finite
+// half-precision numbers in increasing order, so v_pk_maximum3_f16 is a packed 3-way INTEGER max on them (the scorer's
+// premise, checked exhaustively by swmi_selftest_pk_max3; the denormal patterns below 1024 need MODE.FP_DENORM kept).
+// Written with the compiler's own vector builtins, not inline assembly: hipcc forms v_pk_maximum3_f16 from the nested
+// maximum, knows the VOP3P result hazard and schedules around it.
+typedef _Float16 sg_half2 __attribute__((ext_vector_type(2)));
+typedef short sg_short2 __attribute__((ext_vector_type(2)));
+typedef unsigned short sg_ushort2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sg_pk_max3(unsigned a, unsigned b, unsigned c)
+{
+    const sg_half2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(sg_half2, a), __builtin_bit_cast(sg_half2, b)),
+                                                     __builtin_bit_cast(sg_half2, c));
+    return __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ unsigned sg_pk_below(unsigned v, unsigned limit)      // 0xFFFF in every half with v < limit (both < 0x8000)
+{
+    const sg_short2 d = (__builtin_bit_cast(sg_short2, v) - __builtin_bit_cast(sg_short2, limit)) >> 15;
+    return __builtin_bit_cast(unsigned, d);
+}
+__device__ __forceinline__ unsigned sg_pk_sub_sat(unsigned v, unsigned d)        // max(v - d, 0) in every half: v_pk_sub_u16 ... clamp
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(sg_ushort2, v), __builtin_bit_cast(sg_ushort2, d)));
+}
+__device__ __forceinline__ void sg_keep_f16_denormals()                          // MODE.FP_DENORM[7:6] = 3 (hipcc's default, pinned)
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
+}
+
 // ---- sweep, G lanes per alignment (C = 32 / G band cells per lane) -------------------------------------------------
 //
 // Same results as sg_forward_kernel, different mapping: each lane keeps C cells of the band in registers, so most of a
@@ -266,7 +300,7 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
 // Stored value of a cell between rounds: value * 128 + (first cell of the lane) * 4  ("clean"; the lane's share of the
 // index stays in, the cell's own share and the tag are added with the candidate constants).
 
-template <int G, int W>
+template <int G, int W, bool PK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
                         uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
@@ -335,12 +369,16 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const int first_mask = keep_opaque(is_first ? -1 : 0), last_mask = keep_opaque(is_last ? -1 : 0);
     // Clean cells of the previous round, and its shifted view S in TWO register sets that swap roles every round (the
     // round loop is unrolled by two): a single set costs a register copy per cell per round.
-    int cur[C], sp_a[C + 1], sp_b[C + 1];
+    // (PK: NV = C / 2 registers, register k = cells k (low half) and k + NV (high half); see the round below)
+    constexpr int NV = PK ? C / 2 : C;
+    int cur[NV], sp_a[NV + 1], sp_b[NV + 1];
 #pragma unroll
-    for (int c = 0; c < C; ++c) cur[c] = kDropped;
+    for (int c = 0; c < NV; ++c) cur[c] = PK ? 0 : kDropped;
 #pragma unroll
-    for (int c = 0; c <= C; ++c) sp_a[c] = sp_b[c] = kDropped;
-    if (is_last) cur[C - 1] = kXDrop * kScale + lane_base;
+    for (int c = 0; c <= NV; ++c) sp_a[c] = sp_b[c] = PK ? 0 : kDropped;
+    if (is_last) cur[NV - 1] = PK ? ((kXDrop - kPkBase0) * kScale) << 16 : kXDrop * kScale + lane_base;
+    int off = kPkBase0;                                   // PK: true value = stored value + off (off = base - round)
+    if constexpr (PK) sg_keep_f16_denormals();
     // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
     win_t aw = 0, bw = 0;
     {
@@ -411,17 +449,31 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     };
 
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
-    auto one_round = [&](const int round, const int (&sp)[C + 1], int (&sp_next)[C + 1]) {
-        // source.cpp:1895: band cell 0 against band cell 31 (the last lane's values carry its share of the index)
-        const bool right = group_first(cur[0]) + (((G - 1) * C) << 2) < group_last(cur[C - 1]);
+    auto one_round = [&](const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
+        // source.cpp:1895: band cell 0 against band cell 31 (int32 form: the last lane's values carry its share of the index)
+        bool right;
+        if constexpr (PK) right = ((unsigned)group_first(cur[0]) & 0xFFFFu) < ((unsigned)group_last(cur[NV - 1]) >> 16);
+        else              right = group_first(cur[0]) + (((G - 1) * C) << 2) < group_last(cur[C - 1]);
         const int rmask = keep_opaque(right ? -1 : 0);
         pos_x -= rmask;                                   // += 1 when the band steps right
         dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);   // (dir_word >> 1) | (right << 31)
         const int pos_y = round - (pos_x - 31);
         alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
-        // neighbours of the slice in the previous round's band, re-based to this lane's share of the index
-        const int p_lo = from_prev(cur[C - 1]) + (C << 2), p_hi = from_next(cur[0]) - (C << 2);
-        const int lo_in = pick(first_mask, kDropped, p_lo), hi_in = pick(last_mask, kDropped, p_hi);
+        // neighbours of the slice in the previous round's band
+        int lo_in, hi_in;
+        if constexpr (PK) {
+            // register "-1" = cells (-1, NV - 1), register "NV" = cells (NV, C): the neighbour lane's end cell in one half, this
+            // lane's own middle cell in the other (0 = dropped past the band's ends)
+            const unsigned p_lo = (unsigned)from_prev(cur[NV - 1]) & ~(unsigned)first_mask;      // high half: cell -1
+            const unsigned p_hi = (unsigned)from_next(cur[0]) & ~(unsigned)last_mask;            // low half: cell C
+            lo_in = (int)__builtin_amdgcn_alignbit((unsigned)cur[NV - 1], p_lo, 16);             // (cell -1, cell NV - 1)
+            hi_in = (int)__builtin_amdgcn_alignbit(p_hi, (unsigned)cur[0], 16);                  // (cell NV, cell C)
+        } else {
+            // re-based to this lane's share of the index
+            const int p_lo = from_prev(cur[C - 1]) + (C << 2), p_hi = from_next(cur[0]) - (C << 2);
+            lo_in = pick(first_mask, kDropped, p_lo);
+            hi_in = pick(last_mask, kDropped, p_hi);
+        }
         // sequence windows follow the band
         {
             const unsigned s_lo = (unsigned)sreg, s_hi = (unsigned)(sreg >> 32);
@@ -449,8 +501,73 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const win_t mt = ~z & kOnes;                      // bit 4c set: cell c is a match
         const unsigned mt_lo = (unsigned)mt, mt_hi = (unsigned)((unsigned long long)mt >> 32);
 
-        int kmax = (int)0x80000000;
+        int kmax;
         unsigned tags = 0;                                // two tag bits per cell, cell c ends up at bits 2c (C = 16) / 16 + 2c (C = 8)
+        if constexpr (PK) {
+            // match bits as bytes: cells 0, 2, 4, .. in `even`, cells 1, 3, 5, .. in `odd` (bit 0 of byte j = cell 2j / 2j + 1);
+            // ONE v_perm_b32 per register then puts the low cell's byte into byte 1 and the high cell's into byte 3:
+            // 256 = 2 * kScale in the half of a matching cell
+            constexpr unsigned kByteOnes = 0x01010101u;
+            const unsigned even_lo = mt_lo & kByteOnes, odd_lo = (mt_lo >> 4) & kByteOnes;
+            const unsigned even_hi = C == 16 ? mt_hi & kByteOnes : even_lo, odd_hi = C == 16 ? (mt_hi >> 4) & kByteOnes : odd_lo;
+            unsigned v[NV];
+            // S of cells (k, k + NV), k = 0 .. NV: left of register k is sv[k], up is sv[k + 1]
+            unsigned sv[NV + 1];
+            sv[0] = (unsigned)pick(rmask, cur[0], lo_in);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) sv[k + 1] = (unsigned)pick(rmask, k + 1 < NV ? cur[k + 1] : hi_in, cur[k]);
+            // index and tag of the gap candidates: TWO registers per v_lshl_add_u64 (no half ever carries: all stay < 0x7C00).
+            // left of (2m, 2m + 1) and up of (2m - 1, 2m) start from the same register pair (sv[2m], sv[2m + 1]).
+            auto both = [](int k) { return (unsigned)(k << 2) | ((unsigned)((k + NV) << 2) << 16); };   // the two cell indices
+            unsigned vl[NV], vu[NV];
+#pragma unroll
+            for (int m = 0; m < NV / 2; ++m) {
+                const unsigned long long pair = (unsigned long long)sv[2 * m] | ((unsigned long long)sv[2 * m + 1] << 32);
+                const unsigned long long l = pair + (((unsigned long long)(both(2 * m + 1) + 0x00010001u) << 32) | (both(2 * m) + 0x00010001u));
+                vl[2 * m] = (unsigned)l;
+                vl[2 * m + 1] = (unsigned)(l >> 32);
+                if (m > 0) {
+                    const unsigned long long u = pair + (((unsigned long long)(both(2 * m) + 0x00020002u) << 32) | (both(2 * m - 1) + 0x00020002u));
+                    vu[2 * m - 1] = (unsigned)u;
+                    vu[2 * m] = (unsigned)(u >> 32);
+                }
+            }
+            vu[0] = sv[1] + (both(0) + 0x00020002u);
+            vu[NV - 1] = sv[NV] + (both(NV - 1) + 0x00020002u);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int dsel = pick(rmask, sp[k + 1], sp[k]);                                   // diagonal
+                // cell k = byte k / 2 of even / odd (low word), cell k + NV = the same byte of the high word (C = 16) or
+                // byte k / 2 + 2 of the same word (C = 8)
+                const unsigned j = (unsigned)k >> 1;
+                const unsigned sel = 0x000C000Cu | (j << 8) | ((C == 16 ? 4u + j : j + 2u) << 24);
+                const unsigned f = __builtin_amdgcn_perm(k & 1 ? odd_hi : even_hi, k & 1 ? odd_lo : even_lo, sel);
+                const unsigned vd = (unsigned)dsel + f + (both(k) + 0x00030003u + (unsigned)kScale * 0x10001u);   // dia + 3 / dia + 1, tag 3
+                v[k] = sg_pk_max3(vd, vu[k], vl[k]);                                              // up + 0, tag 2; left + 0, tag 1
+                sp_next[k] = (int)sv[k];
+            }
+            sp_next[NV] = (int)sv[NV];
+            // band maximum: a tree of 3-way maxima (depth 2), not a chain
+            unsigned kmax2;
+            if constexpr (NV == 8) kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), sg_pk_max3(v[3], v[4], v[5]), sg_pk_max3(v[6], v[7], v[7]));
+            else                   kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), v[3], v[3]);
+            // tags, cell c at bits 2c of the lane's record.  C = 16: one v_perm_b32 gathers the low bytes of registers k and
+            // k + 4 as (cell k, cell k + 4, cell k + 8, cell k + 12), one mask keeps the four tags, four such words shifted
+            // together give byte j = cells 4j .. 4j + 3
+            if constexpr (NV == 8) {
+#pragma unroll
+                for (int k = 3; k >= 0; --k)
+                    tags = (tags << 2) | (__builtin_amdgcn_perm(v[k + 4], v[k], 0x06020400u) & 0x03030303u);
+            } else {
+#pragma unroll
+                for (int k = NV - 1; k >= 0; --k) tags = (tags << 2) | (v[k] & 0x00030003u);      // cell k at bits 2k, cell k + NV at 16 + 2k
+            }
+            const unsigned k_lo = kmax2 & 0xFFFFu, k_hi = kmax2 >> 16;
+            kmax = (int)(k_lo > k_hi ? k_lo : k_hi) + lane_base;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) cur[k] = (int)v[k];                  // (tagged until the X-drop pass below cleans it)
+        } else {
+        kmax = (int)0x80000000;
         int s_lo_v = pick(rmask, cur[0], lo_in);          // S[0]
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -472,16 +589,39 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             s_lo_v = s_hi_v;
         }
         sp_next[C] = s_lo_v;
+        }
         kmax = group_max(kmax);
-        const int band_best = kmax >> 7;                  // arithmetic shift: the value part of the winner
-        const int round_best = band_best > 0 ? band_best : 0;
+        int round_best;
+        if constexpr (PK) {
+            // stored values are offset: true = stored + off.  A candidate derived from live cells is >= kPkFloor - 2 >= 4, one
+            // derived only from dropped cells (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
+            --off;
+            const int stored = kmax >> 7, band_best = stored + off;
+            round_best = stored > 3 && band_best > 0 ? band_best : 0;
+        } else {
+            const int band_best = kmax >> 7;              // arithmetic shift: the value part of the winner
+            round_best = band_best > 0 ? band_best : 0;
+        }
         const bool improved = alive && round_best > best; // :1933-1936
         const int imask = keep_opaque(improved ? -1 : 0);
         best = pick(imask, round_best, best);
         best_round = pick(imask, round, best_round);
         best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
         best_top = pick(imask, pos_y, best_top);
-        const int thr = (best - kXDrop > 1 ? best - kXDrop : 1) * kScale;     // :1938-1941, and "0 means dropped"
+        const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941, and "0 means dropped"
+        if constexpr (PK) {
+            const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);     // v_mul_u32_u24, full rate
+#pragma unroll
+            for (int k = 0; k < NV; ++k)                  // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
+                cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+            if (C == 8) {
+                my_stage0[8 * (round & 15)] = (uint8_t)tags;
+                my_stage0[8 * (round & 15) + 1] = (uint8_t)(tags >> 16);
+            } else {
+                *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
+            }
+        } else {
+        const int thr = thr_true * kScale;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             // sub, shift, v_bitop3_b32 (0xA8 = (a | b) & c), all full rate; opaque, or hipcc turns it back into a half-rate
@@ -491,12 +631,24 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
         if (C == 8) *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15)) = (uint16_t)(tags >> 16);
         else        *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
+        }
         if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
             flush_codes(round >> 4);
             top_up();
             if ((round & 31) == 31) {
                 if (real && is_first) *my_dirs = dir_word;
                 my_dirs += n;
+            }
+            if constexpr (PK) {
+                // re-base: the threshold (which climbs by one or two a round in stored terms) goes back to kPkFloor; dropped
+                // cells stay 0 (saturating), live ones -- this round's and the view of the round before -- are well above
+                const int delta = (thr_true - off) - kPkFloor;
+                const unsigned d2 = __umul24((unsigned)delta, (unsigned)kScale * 0x10001u);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) cur[k] = (int)sg_pk_sub_sat((unsigned)cur[k], d2);
+#pragma unroll
+                for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
+                off += delta;
             }
         }
         alive = alive && round_best != 0;                 // :1943-1946
@@ -896,6 +1048,8 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
     }
     return sweep;
 }
+// 200 + 10 G + W: the PK form (two cells per register) of the split sweep
+inline bool sweep_is_split(int sweep) { return (sweep >= 21 && sweep <= 44) || (sweep >= 221 && sweep <= 244); }
 bool choose_lane_traceback(size_t n, const SgTuning &tuning)
 {
     return tuning.force_traceback >= 0 ? tuning.force_traceback == 1 : n >= kLaneTracebackMinBatch;
@@ -907,12 +1061,13 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
 {
     const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep_name && sweep_len) {
-        if (sweep != 0 && sweep < 100) snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep / 10, sweep % 10);
+        if (sweep_is_split(sweep))
+            snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d, %s>", sweep % 100 / 10, sweep % 10, sweep > 200 ? "true" : "false");
         else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
     }
     if (tb_name && tb_len)
         snprintf(tb_name, tb_len, "%s", !choose_lane_traceback(n, tuning) ? "sg_traceback_kernel"
-                                        : sweep != 0 && sweep < 100 ? "sg_walk_lane_kernel<1> + sg_expand_kernel"
+                                        : sweep_is_split(sweep) ? "sg_walk_lane_kernel<1> + sg_expand_kernel"
                                                                     : "sg_walk_lane_kernel<0> + sg_expand_kernel");
 }
 
@@ -930,30 +1085,38 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     const int sweep = choose_sweep(n, compute_units, tuning);
-    if (sweep != 0 && sweep < 100) {
-        const uint32_t per_block = sweep / 10 == 4 ? 16 : 32;               // alignments per sweep wavefront: 64 / G
+    if (sweep_is_split(sweep)) {
+        const uint32_t per_block = sweep % 100 / 10 == 4 ? 16 : 32;         // alignments per sweep wavefront: 64 / G
         const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
                            (uint32_t)n, streams, per_block);
         const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32));
-#define SWMI_SG_LAUNCH(G, W, GRID) \
-    hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+#define SWMI_SG_LAUNCH(G, W, PK, GRID) \
+    hipLaunchKernelGGL((sg_forward_split_kernel<G, W, PK>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
         switch (sweep) {
-        case 41: SWMI_SG_LAUNCH(4, 1, grid4); break;
-        case 42: SWMI_SG_LAUNCH(4, 2, grid4); break;
-        case 43: SWMI_SG_LAUNCH(4, 3, grid4); break;
-        case 44: SWMI_SG_LAUNCH(4, 4, grid4); break;
-        case 21: SWMI_SG_LAUNCH(2, 1, grid2); break;
-        case 22: SWMI_SG_LAUNCH(2, 2, grid2); break;
-        case 23: SWMI_SG_LAUNCH(2, 3, grid2); break;
-        case 24: SWMI_SG_LAUNCH(2, 4, grid2); break;
+        case 41: SWMI_SG_LAUNCH(4, 1, false, grid4); break;
+        case 42: SWMI_SG_LAUNCH(4, 2, false, grid4); break;
+        case 43: SWMI_SG_LAUNCH(4, 3, false, grid4); break;
+        case 44: SWMI_SG_LAUNCH(4, 4, false, grid4); break;
+        case 21: SWMI_SG_LAUNCH(2, 1, false, grid2); break;
+        case 22: SWMI_SG_LAUNCH(2, 2, false, grid2); break;
+        case 23: SWMI_SG_LAUNCH(2, 3, false, grid2); break;
+        case 24: SWMI_SG_LAUNCH(2, 4, false, grid2); break;
+        case 241: SWMI_SG_LAUNCH(4, 1, true, grid4); break;
+        case 242: SWMI_SG_LAUNCH(4, 2, true, grid4); break;
+        case 243: SWMI_SG_LAUNCH(4, 3, true, grid4); break;
+        case 244: SWMI_SG_LAUNCH(4, 4, true, grid4); break;
+        case 221: SWMI_SG_LAUNCH(2, 1, true, grid2); break;
+        case 222: SWMI_SG_LAUNCH(2, 2, true, grid2); break;
+        case 223: SWMI_SG_LAUNCH(2, 3, true, grid2); break;
+        case 224: SWMI_SG_LAUNCH(2, 4, true, grid2); break;
         default: return hipErrorInvalidValue;
         }
 #undef SWMI_SG_LAUNCH
     } else {
         const unsigned waves = (unsigned)((n + 1) / 2);
         const dim3 grid((waves + 3) / 4);
-        const int w = sweep > 100 ? sweep - 100 : 0;
+        const int w = sweep > 100 && sweep <= 103 ? sweep - 100 : 0;
         if (w == 1) hipLaunchKernelGGL(sg_forward_kernel<1>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
         else if (w == 2) hipLaunchKernelGGL(sg_forward_kernel<2>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
         else if (w == 3) hipLaunchKernelGGL(sg_forward_kernel<3>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
@@ -965,7 +1128,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     const bool lane_tb = choose_lane_traceback(n, tuning);
     if (lane_tb) {
         // the record format follows the sweep: packed tags from the split sweeps, two ballot words from the half-wavefront one
-        if (sweep != 0 && sweep < 100)
+        if (sweep_is_split(sweep))
             hipLaunchKernelGGL(sg_walk_lane_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
                                summary, moves, d_scores, d_lengths);
         else
