@@ -198,7 +198,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
 //
 // The band consumes seq1 top to bottom and seq2 left to right, one character per move, and only ever the next one.  A
 // pre-pass rewrites both sequences of every alignment as streams of 4-bit fields, 16 per 64-bit word: the base (0..3), and
-// past the end of the sequence the pad the reference appends (source.cpp:1861-1873) -- 8 for seq1, 4 for seq2, so that a
+// past the end of the sequence the pad the reference appends (source.cpp:1861-1873) -- 4 for seq1, 5 for seq2, so that a
 // pad never equals a base or the other pad.  The sweep then needs no index arithmetic, range checks or byte extraction:
 // next character = low field of a 64-bit shift register, topped up every 16 rounds from prefetched words.
 // Layout: the streams of the A alignments one sweep wavefront owns are interleaved word by word,
@@ -206,6 +206,7 @@ sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__
 // because the lanes of a wavefront ask for (nearly) the same word index at the same time: their 8-byte loads then fall
 // into the same few 64-byte lines (with one stream after the other per alignment, every 8-byte load pulled in a line of
 // its own and each line was fetched up to eight times: 10 GB of fetches for 1.1 GB of streams at 65536 alignments).
+constexpr unsigned kPadSeq1 = 4u, kPadSeq2 = 5u;          // three bits: the match test ORs three bits of the XOR
 constexpr int kStreamWords = (kLen + 128) / 16;          // 16 fields per word; 128 fields of pad cover every read-ahead
 
 __global__ void __launch_bounds__(256)
@@ -225,7 +226,7 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
     unsigned long long out;
     if (j < (uint32_t)(kLen / 16)) {
         const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * j);
-        const unsigned pad = second ? 4u : 8u;
+        const unsigned pad = second ? kPadSeq2 : kPadSeq1;
         auto squeeze = [pad](unsigned v) -> unsigned long long {          // 4 bytes -> 4 fields
             unsigned r = 0;
 #pragma unroll
@@ -237,7 +238,7 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         };
         out = squeeze(b.x) | (squeeze(b.y) << 16) | (squeeze(b.z) << 32) | (squeeze(b.w) << 48);
     } else {
-        out = second ? 0x4444444444444444ull : 0x8888888888888888ull;
+        out = (second ? kPadSeq2 : kPadSeq1) * 0x1111111111111111ull;
     }
     streams[t] = out;
 }
@@ -295,7 +296,7 @@ __device__ __forceinline__ void sg_keep_f16_denormals()                         
 //     index and tag: cur = (V0 | sign(V0 - threshold)) & clean_mask -- sub, shift, v_bitop3, all full rate;
 //   * the shifted views S[j] = right ? P[j] : P[j-1] (left = S[c], up = S[c+1]; last round's view gives the diagonal) are
 //     bitwise selects with a per-lane all-ones / all-zeros mask: v_bitop3_b32 (full rate) instead of v_cndmask (half);
-//   * sequence characters are 4-bit fields (0..3, pads 8 / 4: a pad never matches) in one window per sequence, cell c <->
+//   * sequence characters are 4-bit fields (0..3, pads 4 / 5: a pad never matches) in one window per sequence, cell c <->
 //     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells.
 // Stored value of a cell between rounds: value * 128 + (first cell of the lane) * 4  ("clean"; the lane's share of the
 // index stays in, the cell's own share and the tag are added with the candidate constants).
@@ -309,7 +310,6 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     constexpr int A = 64 / G;                             // alignments per wavefront
     static_assert(G == 2 || G == 4, "the cross-lane moves below are written for quads");
     using win_t = typename std::conditional<C == 8, uint32_t, unsigned long long>::type;   // C 4-bit fields
-    constexpr win_t kOnes = (win_t)0x1111111111111111ull;
     // sixteen rounds of code records per alignment are staged here and leave as ONE 128-byte line per alignment: a
     // 64-byte piece of a 128-byte L2 line costs a read-for-ownership of the whole line on top of the write
     __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]
@@ -387,8 +387,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         for (int c = 0; c < C; ++c) {
             const int i1 = 30 - (g * C + c);                                  // differs per lane: shifts, not indexing
             const unsigned ch = (unsigned)(((i1 & 16) ? w1 : w0) >> (4 * (i1 & 15))) & 15u;
-            aw |= (win_t)(i1 >= 0 ? ch : 8u) << (4 * c);
-            bw |= (win_t)4u << (4 * c);
+            aw |= (win_t)(i1 >= 0 ? ch : kPadSeq1) << (4 * c);
+            bw |= (win_t)kPadSeq2 << (4 * c);
         }
     }
     int pos_x = 31;
@@ -407,7 +407,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // and copies it every round, which puts an s_waitcnt vmcnt(0) -- on the load AND on the record stores -- into every round.
     const unsigned long long *my_stream = is_last ? stream_b : stream_a;
     unsigned long long sreg, pend, ahead;
-    int p_fill, w_next, used = 0;
+    int p_fill, w_next, used4 = 0;                        // used4 = 4 * characters consumed since the last top-up
     {
         const int s_idx = is_last ? 0 : 31;               // next character: seq2[0] / seq1[31]
         const int c0 = s_idx & 15, w0i = s_idx >> 4;
@@ -418,9 +418,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         ahead = my_stream[(w0i + 2) * kStreamStride];
         w_next = w0i + 3;
     }
-    auto top_up = [&]() {                                 // `used` characters consumed since the last call: refill sreg to 16
-        const int k = used;
-        used = 0;
+    auto top_up = [&]() {                                 // used4 / 4 characters consumed since the last call: refill sreg to 16
+        const int k = used4 >> 2;
+        sreg = k < 16 ? sreg >> used4 : 0ull;             // (between top-ups the round reads its character at bit used4: no shift per round)
+        used4 = 0;
         const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
         // pend's first `from_pend` characters go behind the 16 - k that are left; whatever of pend does not fit falls off the top
         const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;
@@ -436,15 +437,6 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         } else {
             pend = from_pend ? pend >> (4 * from_pend) : pend;
             p_fill -= from_pend;
-        }
-    };
-    auto pick_win = [&](int m, win_t if_set, win_t if_clear) -> win_t {
-        if constexpr (C == 8) {
-            return (win_t)pick(m, (int)if_set, (int)if_clear);
-        } else {
-            const unsigned lo = (unsigned)pick(m, (int)(unsigned)if_set, (int)(unsigned)if_clear);
-            const unsigned hi = (unsigned)pick(m, (int)(unsigned)(if_set >> 32), (int)(unsigned)(if_clear >> 32));
-            return ((win_t)hi << 32) | lo;
         }
     };
 
@@ -476,30 +468,25 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
         // sequence windows follow the band
         {
-            const unsigned s_lo = (unsigned)sreg, s_hi = (unsigned)(sreg >> 32);
-            const unsigned cand = s_lo & 15u;             // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
+            const unsigned cand = (unsigned)(sreg >> used4) & 15u;            // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
             const unsigned a_top = (unsigned)(aw >> (4 * C - 4)), b_low = (unsigned)bw & 15u;
             // (the DPP moves are evaluated by ALL lanes before the select: inside one arm of `?:` they would run with the
             // source lanes masked off)
             const unsigned a_nb = (unsigned)from_prev((int)a_top), b_nb = (unsigned)from_next((int)b_low);
             const unsigned a_in = (unsigned)pick(first_mask, (int)cand, (int)a_nb);
             const unsigned b_in = (unsigned)pick(last_mask, (int)cand, (int)b_nb);
-            const win_t aw_d = (aw << 4) | a_in;
-            const win_t bw_r = (bw >> 4) | ((win_t)b_in << (4 * C - 4));
-            aw = pick_win(rmask, aw, aw_d);
-            bw = pick_win(rmask, bw_r, bw);
+            // aw moves up one field when the band steps down, bw moves down one field when it steps right: a shift by 0 or 4
+            // (one variable 64-bit shift each) and the entering character masked in -- not two shifted copies and a select
+            const unsigned shift_a = 4u & ~(unsigned)rmask, shift_b = 4u & (unsigned)rmask;
+            aw = (aw << shift_a) | (win_t)(a_in & ~(unsigned)rmask);
+            bw = (bw >> shift_b) | ((win_t)(b_in & (unsigned)rmask) << (4 * C - 4));
             const int cmask = keep_opaque(~(rmask ^ last_mask));              // consume = is_last ? right : !right
-            const unsigned sh_lo = __builtin_amdgcn_alignbit(s_hi, s_lo, 4), sh_hi = s_hi >> 4;
-            const unsigned n_lo = (unsigned)pick(cmask, (int)sh_lo, (int)s_lo);
-            const unsigned n_hi = (unsigned)pick(cmask, (int)sh_hi, (int)s_hi);
-            sreg = ((unsigned long long)n_hi << 32) | n_lo;
-            used -= cmask;
+            used4 += cmask & 4;
         }
-        win_t z = aw ^ bw;
-        z |= z >> 1;
-        z |= z >> 2;
-        const win_t mt = ~z & kOnes;                      // bit 4c set: cell c is a match
-        const unsigned mt_lo = (unsigned)mt, mt_hi = (unsigned)((unsigned long long)mt >> 32);
+        // a field of aw ^ bw is 0..7 (the codes have three bits): bit 0 of  z | z >> 1 | z >> 2  = "the characters differ"
+        const win_t z = aw ^ bw;
+        const win_t differ = z | (z >> 1) | (z >> 2);                         // bit 4c clear: cell c is a match
+        const unsigned df_lo = (unsigned)differ, df_hi = (unsigned)((unsigned long long)differ >> 32);
 
         int kmax;
         unsigned tags = 0;                                // two tag bits per cell, cell c ends up at bits 2c (C = 16) / 16 + 2c (C = 8)
@@ -508,8 +495,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             // ONE v_perm_b32 per register then puts the low cell's byte into byte 1 and the high cell's into byte 3:
             // 256 = 2 * kScale in the half of a matching cell
             constexpr unsigned kByteOnes = 0x01010101u;
-            const unsigned even_lo = mt_lo & kByteOnes, odd_lo = (mt_lo >> 4) & kByteOnes;
-            const unsigned even_hi = C == 16 ? mt_hi & kByteOnes : even_lo, odd_hi = C == 16 ? (mt_hi >> 4) & kByteOnes : odd_lo;
+            const unsigned even_lo = ~df_lo & kByteOnes, odd_lo = ~(df_lo >> 4) & kByteOnes;
+            const unsigned even_hi = C == 16 ? ~df_hi & kByteOnes : even_lo, odd_hi = C == 16 ? ~(df_hi >> 4) & kByteOnes : odd_lo;
             unsigned v[NV];
             // S of cells (k, k + NV), k = 0 .. NV: left of register k is sv[k], up is sv[k + 1]
             unsigned sv[NV + 1];
@@ -574,7 +561,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             const int above = c + 1 < C ? cur[c + 1] : hi_in;                 // P[c+1]
             const int s_hi_v = pick(rmask, above, cur[c]);                    // S[c+1]: up (:1899-1900 / :1909)
             const int dsel = pick(rmask, sp[c + 1], sp[c]);                   // diagonal (:1897 / :1908)
-            const unsigned mw = c < 8 ? mt_lo : mt_hi;
+            const unsigned mw = ~(c < 8 ? df_lo : df_hi);
             const int sh = 4 * (c & 7) - 8;                                   // match bit -> bit 8 = 2 * kScale
             const int f = (int)((sh >= 0 ? mw >> sh : mw << -sh) & (2u * kScale));
             const int vd = dsel + f + ((c << 2) + 3 - kScale);                // dia + 1 / dia - 1, tag 3   (:1918-1922)
@@ -655,10 +642,13 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         last_round = round;
     };
 
-    for (int round = 1; round < kMaxRound; round += 2) {  // kMaxRound is odd: rounds 1 .. kMaxRound - 1 in pairs
-        if (!__any(alive)) break;
+    // kMaxRound is odd: rounds 1 .. kMaxRound - 1 in pairs.  "Has every alignment of the wavefront ended" is asked once per
+    // 16 rounds, not per round: the test is a vector compare feeding a scalar branch, which drains the wavefront's pipeline;
+    // the up to 15 rounds a finished wavefront runs on change nothing (no alignment is alive to improve, and the records of
+    // rounds after an alignment's best round are never read).
+    for (int round = 1; round < kMaxRound; round += 2) {
+        if ((round & 15) == 1 && !__any(alive)) break;
         one_round(round, sp_a, sp_b);
-        if (!__any(alive)) break;
         one_round(round + 1, sp_b, sp_a);
     }
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
