@@ -404,11 +404,13 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
     sweep_kernel, tb_kernel = swmi.semiglobal_kernels_for_batch(P)          # the library says which mapping it ran
     name = sweep_kernel.replace(" ", "")
-    # wavefronts of the sweep: 32 / 16 alignments per wavefront with the band over 2 / 4 lanes, 2 with a band per half-wavefront
-    per_wave = {"sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(name.split(",")[0], 2)
-    # the split sweep's round loop is unrolled by two; one v_alignbit per cell + the stream / window shifts mark a round
-    # (per round: one v_alignbit per cell, one for the move bit, one / two for the stream and window shifts)
-    marker = {"sg_forward_split_kernel<2": ("v_alignbit_b32", 19), "sg_forward_split_kernel<4": ("v_alignbit_b32", 10)}.get(name.split(",")[0])
+    # wavefronts of the sweep: 64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes, 2 with a band per half-wavefront
+    family = name.split(",")[0]
+    per_wave = {"sg_forward_lane_kernel<1": 64, "sg_forward_lane_kernel<2": 64, "sg_forward_lane_kernel<3": 64, "sg_forward_lane_kernel<4": 64,
+                "sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(family, 2)
+    # the sweeps' round loop is unrolled by two; the X-drop test's one v_pk_ashrrev_i16 per register (two cells) marks a round
+    marker = ("v_pk_ashrrev_i16", 16) if family.startswith("sg_forward_lane_kernel") else \
+        {"sg_forward_split_kernel<2": ("v_pk_ashrrev_i16", 8), "sg_forward_split_kernel<4": ("v_pk_ashrrev_i16", 4)}.get(family)
     # the record flush + stream top-up block runs on every 16th round; the loop holds two rounds and hipcc keeps one copy
     # of the block behind each, so of the conditional instructions the census finds in a trip 1/16 run on average
     roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker, conditional_share=1.0 / 16)

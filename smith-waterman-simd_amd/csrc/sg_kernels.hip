@@ -43,7 +43,6 @@ __device__ __forceinline__ size_t code_index(uint32_t n, uint32_t a, int round) 
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
 constexpr int kDirWords = kMaxRound / 32 + 1;
 // which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
-constexpr size_t kSplit4MinBatch = 4096;         // band over 4 (later 2) lanes from here on
 constexpr size_t kLaneTracebackMinBatch = 2048;  // one lane per walk (+ expand kernel) from here on
 
 // Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
@@ -94,7 +93,7 @@ __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from tu
 // masks, and every cross-lane step is a DPP move or a v_readlane (an LDS-crossbar shuffle costs more than all of a
 // round's arithmetic).  ~95 instructions per round (round 1's formulation: ~128).
 constexpr int kScale = 128;
-// PK form of the split sweep: values are stored as  true + round - base  (a gap or a mismatch step then adds 0 / 1 and a
+// The split and lane sweeps store a cell's value as  true + round - base  (a gap or a mismatch step then adds 0 / 1 and a
 // match 3: nothing negative is ever added to an unsigned half), re-based every 16 rounds so that the X-drop threshold is
 // kPkFloor again; kPkBase0 = the base before round 1 (threshold 1 + 1 - base = kPkFloor).
 constexpr int kPkFloor = 8;
@@ -243,7 +242,7 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
     streams[t] = out;
 }
 
-// ---- packed 16-bit helpers for the PK form of the split sweep ---------------------------------------------------
+// ---- packed 16-bit helpers of the split and lane sweeps ----------------------------------------------------------
 // Two band cells per register.  Every half is an integer in [0, 0x7C00): as bit patterns those are the non-negative finite
 // half-precision numbers in increasing order, so v_pk_maximum3_f16 is a packed 3-way INTEGER max on them (the scorer's
 // premise, checked exhaustively by swmi_selftest_pk_max3; the denormal patterns below 1024 need MODE.FP_DENORM kept).
@@ -277,31 +276,42 @@ __device__ __forceinline__ void sg_keep_f16_denormals()                         
 // Same results as sg_forward_kernel, different mapping: each lane keeps C cells of the band in registers, so most of a
 // round is plain per-lane arithmetic.  What crosses lanes per round is small: the two cells next to the lane's slice, one
 // sequence character in each direction, the band's two end cells (direction) and the band maximum -- all DPP moves inside
-// a row of 16 lanes.  (A whole band per lane, G = 1, was the first version: 64 alignments per wavefront and ~200 VGPRs
-// leave one or two wavefronts per SIMD and nothing to hide latencies behind; it lost to G = 2 and G = 4 at every batch size.)
+// a row of 16 lanes.
 //
-// The cell (round 2 form: 32 VALU issue cycles per cell, was ~55).  A cell value travels as ONE tagged integer
-//     V = value * 128 + band_cell * 4 + tag                      (kScale = 128: 5 bits of cell index, 2 bits of tag)
-// and the three candidates of a cell carry the tags 3 (diagonal), 2 (up), 1 (left).  Then
-//   * V0 = v_max3(VD, VU, VL) yields the cell's value AND, in its low two bits, which predecessor won -- with the
-//     reference's tie-break order (diagonal, then up, then left; source.cpp:1962-1971) because equal values compare by tag.
-//     No compares, no subtractions: ONE v_alignbit per cell shifts the two tag bits into the lane's code word;
+// The cell (round 3 form: TWO band cells per register; round 2 kept one int32 per cell and ran 13.5 instructions per cell
+// where this runs 5.6 -- profiles/r03_sg_kernel_matrix.txt has both).  A cell value travels as ONE tagged 16-bit integer
+//     V = stored * 128 + band_cell * 4 + tag                     (kScale = 128: 5 bits of cell index, 2 bits of tag)
+//     stored = true value + round - base                          (below)
+// register k of a lane holds cells k (low half) and k + C/2 (high half), and the three candidates of a cell carry the tags
+// 3 (diagonal), 2 (up), 1 (left).  Then
+//   * V0 = v_pk_maximum3_f16(VD, VU, VL) yields, for both cells, the value AND in its low two bits which predecessor won --
+//     with the reference's tie-break order (diagonal, then up, then left; source.cpp:1962-1971) because equal values compare
+//     by tag.  Every half stays below 0x7C00, where the half-precision order of the bit patterns is the integer order (the
+//     scorer's premise, swmi_selftest_pk_max3);
 //   * all three candidates of a cell carry the same cell index, so the index never influences the cell's own max, while
 //     the band maximum max(V0 over cells and lanes) is decided by value, then by the HIGHEST cell index among equals --
 //     where the reference's search stops (source.cpp:1957-1958); the tag never matters there (indices differ);
-//   * the "-1" of a gap move and of a mismatch is folded into the per-candidate constant (cell * 4 + tag - 128), a match
-//     adds 256;
-//   * a dropped cell holds value -1 (the reference stores 0 and guards with != 0, source.cpp:1922-1924): every candidate
-//     derived from dropped cells is <= 0 < max(best - 70, 1) and is dropped again by the X-drop test, which also strips
-//     index and tag: cur = (V0 | sign(V0 - threshold)) & clean_mask -- sub, shift, v_bitop3, all full rate;
-//   * the shifted views S[j] = right ? P[j] : P[j-1] (left = S[c], up = S[c+1]; last round's view gives the diagonal) are
-//     bitwise selects with a per-lane all-ones / all-zeros mask: v_bitop3_b32 (full rate) instead of v_cndmask (half);
+//   * nothing negative is ever added to an unsigned half: a stored value is  true + round - base,  so a gap step (true - 1,
+//     one round later) adds 0, a mismatch (true - 1, two rounds later) adds 1 and a match adds 3.  The X-drop threshold
+//     climbs by one or two per round in stored terms; every 16 rounds (where the records are flushed anyway) base moves so
+//     that it is kPkFloor again: live values stay below 8 + 32 + 71 + 3 < 248 = 0x7C00 / 128;
+//   * a dropped cell holds 0 (the reference stores 0 and guards with != 0, source.cpp:1922-1924): a candidate derived only
+//     from dropped cells is <= 3 < kPkFloor - 2 <= every live one, is dropped again by the X-drop test and counts as "<= 0"
+//     for the band maximum.  The test is  cur = V0 & ~(V0 < threshold) & clean_mask  per register: v_pk_sub_i16,
+//     v_pk_ashrrev_i16, v_bitop3;
+//   * with cells k and k + C/2 in one register the shifted views S[j] = right ? P[j] : P[j-1] (left = S[c], up = S[c+1]; last
+//     round's view gives the diagonal) are whole registers again: S of register k = right ? register k : register k - 1, one
+//     v_bitop3_b32 select per REGISTER with a per-lane all-ones / all-zeros mask (v_cndmask is half rate); only the two
+//     registers at the slice's ends are assembled from halves (v_alignbit);
+//   * index and tag of the two gap candidates of two registers are added by ONE v_lshl_add_u64 (no half ever carries);
 //   * sequence characters are 4-bit fields (0..3, pads 4 / 5: a pad never matches) in one window per sequence, cell c <->
-//     field c, shifted by one field per move; one XOR + zero-field test per round gives the match bits of all cells.
-// Stored value of a cell between rounds: value * 128 + (first cell of the lane) * 4  ("clean"; the lane's share of the
-// index stays in, the cell's own share and the tag are added with the candidate constants).
+//     field c, shifted by one field per move (a variable 64-bit shift by 0 or 4); XOR + OR of three bits gives the match
+//     bits of all cells, split into bytes of even and odd cells, and one v_perm_b32 per register puts its two cells' bytes
+//     where they add 256 = 2 * kScale;
+//   * the winners' tags: one v_perm_b32 gathers the low bytes of two registers, one mask, one shift-or per pair.
+// Measured (65536 alignments, G = 2): 167 VALU instructions per wavefront-round (round 2: 273.5), 31.2 -> 21.7 ms.
 
-template <int G, int W, bool PK>
+template <int G, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
                         uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
@@ -363,22 +373,20 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // as (b & m) | (c & ~m) hipcc picks v_bfi_b32, written as ?: v_cndmask_b32 -- both half rate on gfx950.
     auto pick = [](int m, int if_set, int if_clear) { return (int)__builtin_amdgcn_bitop3_b32((unsigned)m, (unsigned)if_set, (unsigned)if_clear, 0xCA); };
 
-    const int lane_base = (g * C) << 2;                   // this lane's share of the cell index, where a value carries it
-    const int clean_mask = keep_opaque(~(kScale - 1) | lane_base);            // also the dropped cell: value -1, clean
-    const int kDropped = clean_mask;
+    const int lane_base = (g * C) << 2;                   // this lane's share of the cell index: added to the lane's maximum only
     const int first_mask = keep_opaque(is_first ? -1 : 0), last_mask = keep_opaque(is_last ? -1 : 0);
     // Clean cells of the previous round, and its shifted view S in TWO register sets that swap roles every round (the
     // round loop is unrolled by two): a single set costs a register copy per cell per round.
-    // (PK: NV = C / 2 registers, register k = cells k (low half) and k + NV (high half); see the round below)
-    constexpr int NV = PK ? C / 2 : C;
+    // NV = C / 2 registers, register k = cells k (low half) and k + NV (high half); 0 = dropped.
+    constexpr int NV = C / 2;
     int cur[NV], sp_a[NV + 1], sp_b[NV + 1];
 #pragma unroll
-    for (int c = 0; c < NV; ++c) cur[c] = PK ? 0 : kDropped;
+    for (int c = 0; c < NV; ++c) cur[c] = 0;
 #pragma unroll
-    for (int c = 0; c <= NV; ++c) sp_a[c] = sp_b[c] = PK ? 0 : kDropped;
-    if (is_last) cur[NV - 1] = PK ? ((kXDrop - kPkBase0) * kScale) << 16 : kXDrop * kScale + lane_base;
-    int off = kPkBase0;                                   // PK: true value = stored value + off (off = base - round)
-    if constexpr (PK) sg_keep_f16_denormals();
+    for (int c = 0; c <= NV; ++c) sp_a[c] = sp_b[c] = 0;
+    if (is_last) cur[NV - 1] = ((kXDrop - kPkBase0) * kScale) << 16;         // band cell 31
+    int off = kPkBase0;                                   // true value = stored value + off (off = base - round)
+    sg_keep_f16_denormals();
     // round 0: pos_y = 0, pos_x = 31 -> cell k sits at row 31 - k (valid for k <= 30), column k - 31 (never valid)
     win_t aw = 0, bw = 0;
     {
@@ -442,30 +450,20 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
 
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
     auto one_round = [&](const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
-        // source.cpp:1895: band cell 0 against band cell 31 (int32 form: the last lane's values carry its share of the index)
-        bool right;
-        if constexpr (PK) right = ((unsigned)group_first(cur[0]) & 0xFFFFu) < ((unsigned)group_last(cur[NV - 1]) >> 16);
-        else              right = group_first(cur[0]) + (((G - 1) * C) << 2) < group_last(cur[C - 1]);
+        // source.cpp:1895: band cell 0 (first lane, register 0, low half) against band cell 31 (last lane, last register, high half)
+        const bool right = ((unsigned)group_first(cur[0]) & 0xFFFFu) < ((unsigned)group_last(cur[NV - 1]) >> 16);
         const int rmask = keep_opaque(right ? -1 : 0);
         pos_x -= rmask;                                   // += 1 when the band steps right
         dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);   // (dir_word >> 1) | (right << 31)
         const int pos_y = round - (pos_x - 31);
         alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
         // neighbours of the slice in the previous round's band
-        int lo_in, hi_in;
-        if constexpr (PK) {
-            // register "-1" = cells (-1, NV - 1), register "NV" = cells (NV, C): the neighbour lane's end cell in one half, this
-            // lane's own middle cell in the other (0 = dropped past the band's ends)
-            const unsigned p_lo = (unsigned)from_prev(cur[NV - 1]) & ~(unsigned)first_mask;      // high half: cell -1
-            const unsigned p_hi = (unsigned)from_next(cur[0]) & ~(unsigned)last_mask;            // low half: cell C
-            lo_in = (int)__builtin_amdgcn_alignbit((unsigned)cur[NV - 1], p_lo, 16);             // (cell -1, cell NV - 1)
-            hi_in = (int)__builtin_amdgcn_alignbit(p_hi, (unsigned)cur[0], 16);                  // (cell NV, cell C)
-        } else {
-            // re-based to this lane's share of the index
-            const int p_lo = from_prev(cur[C - 1]) + (C << 2), p_hi = from_next(cur[0]) - (C << 2);
-            lo_in = pick(first_mask, kDropped, p_lo);
-            hi_in = pick(last_mask, kDropped, p_hi);
-        }
+        // register "-1" = cells (-1, NV - 1), register "NV" = cells (NV, C): the neighbour lane's end cell in one half, this
+        // lane's own middle cell in the other (0 = dropped past the band's ends)
+        const unsigned p_lo = (unsigned)from_prev(cur[NV - 1]) & ~(unsigned)first_mask;          // high half: cell -1
+        const unsigned p_hi = (unsigned)from_next(cur[0]) & ~(unsigned)last_mask;                // low half: cell C
+        const int lo_in = (int)__builtin_amdgcn_alignbit((unsigned)cur[NV - 1], p_lo, 16);       // (cell -1, cell NV - 1)
+        const int hi_in = (int)__builtin_amdgcn_alignbit(p_hi, (unsigned)cur[0], 16);            // (cell NV, cell C)
         // sequence windows follow the band
         {
             const unsigned cand = (unsigned)(sreg >> used4) & 15u;            // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
@@ -488,107 +486,75 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const win_t differ = z | (z >> 1) | (z >> 2);                         // bit 4c clear: cell c is a match
         const unsigned df_lo = (unsigned)differ, df_hi = (unsigned)((unsigned long long)differ >> 32);
 
-        int kmax;
-        unsigned tags = 0;                                // two tag bits per cell, cell c ends up at bits 2c (C = 16) / 16 + 2c (C = 8)
-        if constexpr (PK) {
-            // match bits as bytes: cells 0, 2, 4, .. in `even`, cells 1, 3, 5, .. in `odd` (bit 0 of byte j = cell 2j / 2j + 1);
-            // ONE v_perm_b32 per register then puts the low cell's byte into byte 1 and the high cell's into byte 3:
-            // 256 = 2 * kScale in the half of a matching cell
-            constexpr unsigned kByteOnes = 0x01010101u;
-            const unsigned even_lo = ~df_lo & kByteOnes, odd_lo = ~(df_lo >> 4) & kByteOnes;
-            const unsigned even_hi = C == 16 ? ~df_hi & kByteOnes : even_lo, odd_hi = C == 16 ? ~(df_hi >> 4) & kByteOnes : odd_lo;
-            unsigned v[NV];
-            // S of cells (k, k + NV), k = 0 .. NV: left of register k is sv[k], up is sv[k + 1]
-            unsigned sv[NV + 1];
-            sv[0] = (unsigned)pick(rmask, cur[0], lo_in);
+        unsigned tags = 0;                                // two tag bits per cell, cell c at bits 2c of the lane's record
+        // match bits as bytes: cells 0, 2, 4, .. in `even`, cells 1, 3, 5, .. in `odd` (bit 0 of byte j = cell 2j / 2j + 1);
+        // ONE v_perm_b32 per register then puts the low cell's byte into byte 1 and the high cell's into byte 3:
+        // 256 = 2 * kScale in the half of a matching cell
+        constexpr unsigned kByteOnes = 0x01010101u;
+        const unsigned even_lo = ~df_lo & kByteOnes, odd_lo = ~(df_lo >> 4) & kByteOnes;
+        const unsigned even_hi = C == 16 ? ~df_hi & kByteOnes : even_lo, odd_hi = C == 16 ? ~(df_hi >> 4) & kByteOnes : odd_lo;
+        unsigned v[NV];
+        // S of cells (k, k + NV), k = 0 .. NV: left of register k is sv[k], up is sv[k + 1]
+        unsigned sv[NV + 1];
+        sv[0] = (unsigned)pick(rmask, cur[0], lo_in);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) sv[k + 1] = (unsigned)pick(rmask, k + 1 < NV ? cur[k + 1] : hi_in, cur[k]);
-            // index and tag of the gap candidates: TWO registers per v_lshl_add_u64 (no half ever carries: all stay < 0x7C00).
-            // left of (2m, 2m + 1) and up of (2m - 1, 2m) start from the same register pair (sv[2m], sv[2m + 1]).
-            auto both = [](int k) { return (unsigned)(k << 2) | ((unsigned)((k + NV) << 2) << 16); };   // the two cell indices
-            unsigned vl[NV], vu[NV];
+        for (int k = 0; k < NV; ++k) sv[k + 1] = (unsigned)pick(rmask, k + 1 < NV ? cur[k + 1] : hi_in, cur[k]);
+        // index and tag of the gap candidates: TWO registers per v_lshl_add_u64 (no half ever carries: all stay < 0x7C00).
+        // left of (2m, 2m + 1) and up of (2m - 1, 2m) start from the same register pair (sv[2m], sv[2m + 1]).
+        auto both = [](int k) { return (unsigned)(k << 2) | ((unsigned)((k + NV) << 2) << 16); };   // the two cell indices
+        unsigned vl[NV], vu[NV];
 #pragma unroll
-            for (int m = 0; m < NV / 2; ++m) {
-                const unsigned long long pair = (unsigned long long)sv[2 * m] | ((unsigned long long)sv[2 * m + 1] << 32);
-                const unsigned long long l = pair + (((unsigned long long)(both(2 * m + 1) + 0x00010001u) << 32) | (both(2 * m) + 0x00010001u));
-                vl[2 * m] = (unsigned)l;
-                vl[2 * m + 1] = (unsigned)(l >> 32);
-                if (m > 0) {
-                    const unsigned long long u = pair + (((unsigned long long)(both(2 * m) + 0x00020002u) << 32) | (both(2 * m - 1) + 0x00020002u));
-                    vu[2 * m - 1] = (unsigned)u;
-                    vu[2 * m] = (unsigned)(u >> 32);
-                }
+        for (int m = 0; m < NV / 2; ++m) {
+            const unsigned long long pair = (unsigned long long)sv[2 * m] | ((unsigned long long)sv[2 * m + 1] << 32);
+            const unsigned long long l = pair + (((unsigned long long)(both(2 * m + 1) + 0x00010001u) << 32) | (both(2 * m) + 0x00010001u));
+            vl[2 * m] = (unsigned)l;
+            vl[2 * m + 1] = (unsigned)(l >> 32);
+            if (m > 0) {
+                const unsigned long long u = pair + (((unsigned long long)(both(2 * m) + 0x00020002u) << 32) | (both(2 * m - 1) + 0x00020002u));
+                vu[2 * m - 1] = (unsigned)u;
+                vu[2 * m] = (unsigned)(u >> 32);
             }
-            vu[0] = sv[1] + (both(0) + 0x00020002u);
-            vu[NV - 1] = sv[NV] + (both(NV - 1) + 0x00020002u);
+        }
+        vu[0] = sv[1] + (both(0) + 0x00020002u);
+        vu[NV - 1] = sv[NV] + (both(NV - 1) + 0x00020002u);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int dsel = pick(rmask, sp[k + 1], sp[k]);                                   // diagonal
-                // cell k = byte k / 2 of even / odd (low word), cell k + NV = the same byte of the high word (C = 16) or
-                // byte k / 2 + 2 of the same word (C = 8)
-                const unsigned j = (unsigned)k >> 1;
-                const unsigned sel = 0x000C000Cu | (j << 8) | ((C == 16 ? 4u + j : j + 2u) << 24);
-                const unsigned f = __builtin_amdgcn_perm(k & 1 ? odd_hi : even_hi, k & 1 ? odd_lo : even_lo, sel);
-                const unsigned vd = (unsigned)dsel + f + (both(k) + 0x00030003u + (unsigned)kScale * 0x10001u);   // dia + 3 / dia + 1, tag 3
-                v[k] = sg_pk_max3(vd, vu[k], vl[k]);                                              // up + 0, tag 2; left + 0, tag 1
-                sp_next[k] = (int)sv[k];
-            }
-            sp_next[NV] = (int)sv[NV];
-            // band maximum: a tree of 3-way maxima (depth 2), not a chain
-            unsigned kmax2;
-            if constexpr (NV == 8) kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), sg_pk_max3(v[3], v[4], v[5]), sg_pk_max3(v[6], v[7], v[7]));
-            else                   kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), v[3], v[3]);
-            // tags, cell c at bits 2c of the lane's record.  C = 16: one v_perm_b32 gathers the low bytes of registers k and
-            // k + 4 as (cell k, cell k + 4, cell k + 8, cell k + 12), one mask keeps the four tags, four such words shifted
-            // together give byte j = cells 4j .. 4j + 3
-            if constexpr (NV == 8) {
+        for (int k = 0; k < NV; ++k) {
+            const int dsel = pick(rmask, sp[k + 1], sp[k]);                                   // diagonal
+            // cell k = byte k / 2 of even / odd (low word), cell k + NV = the same byte of the high word (C = 16) or
+            // byte k / 2 + 2 of the same word (C = 8)
+            const unsigned j = (unsigned)k >> 1;
+            const unsigned sel = 0x000C000Cu | (j << 8) | ((C == 16 ? 4u + j : j + 2u) << 24);
+            const unsigned f = __builtin_amdgcn_perm(k & 1 ? odd_hi : even_hi, k & 1 ? odd_lo : even_lo, sel);
+            const unsigned vd = (unsigned)dsel + f + (both(k) + 0x00030003u + (unsigned)kScale * 0x10001u);   // dia + 3 / dia + 1, tag 3
+            v[k] = sg_pk_max3(vd, vu[k], vl[k]);                                              // up + 0, tag 2; left + 0, tag 1
+            sp_next[k] = (int)sv[k];
+        }
+        sp_next[NV] = (int)sv[NV];
+        // band maximum: a tree of 3-way maxima (depth 2), not a chain
+        unsigned kmax2;
+        if constexpr (NV == 8) kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), sg_pk_max3(v[3], v[4], v[5]), sg_pk_max3(v[6], v[7], v[7]));
+        else                   kmax2 = sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), v[3], v[3]);
+        // tags, cell c at bits 2c of the lane's record.  C = 16: one v_perm_b32 gathers the low bytes of registers k and
+        // k + 4 as (cell k, cell k + 4, cell k + 8, cell k + 12), one mask keeps the four tags, four such words shifted
+        // together give byte j = cells 4j .. 4j + 3
+        if constexpr (NV == 8) {
 #pragma unroll
-                for (int k = 3; k >= 0; --k)
-                    tags = (tags << 2) | (__builtin_amdgcn_perm(v[k + 4], v[k], 0x06020400u) & 0x03030303u);
-            } else {
-#pragma unroll
-                for (int k = NV - 1; k >= 0; --k) tags = (tags << 2) | (v[k] & 0x00030003u);      // cell k at bits 2k, cell k + NV at 16 + 2k
-            }
-            const unsigned k_lo = kmax2 & 0xFFFFu, k_hi = kmax2 >> 16;
-            kmax = (int)(k_lo > k_hi ? k_lo : k_hi) + lane_base;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) cur[k] = (int)v[k];                  // (tagged until the X-drop pass below cleans it)
+            for (int k = 3; k >= 0; --k)
+                tags = (tags << 2) | (__builtin_amdgcn_perm(v[k + 4], v[k], 0x06020400u) & 0x03030303u);
         } else {
-        kmax = (int)0x80000000;
-        int s_lo_v = pick(rmask, cur[0], lo_in);          // S[0]
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int above = c + 1 < C ? cur[c + 1] : hi_in;                 // P[c+1]
-            const int s_hi_v = pick(rmask, above, cur[c]);                    // S[c+1]: up (:1899-1900 / :1909)
-            const int dsel = pick(rmask, sp[c + 1], sp[c]);                   // diagonal (:1897 / :1908)
-            const unsigned mw = ~(c < 8 ? df_lo : df_hi);
-            const int sh = 4 * (c & 7) - 8;                                   // match bit -> bit 8 = 2 * kScale
-            const int f = (int)((sh >= 0 ? mw >> sh : mw << -sh) & (2u * kScale));
-            const int vd = dsel + f + ((c << 2) + 3 - kScale);                // dia + 1 / dia - 1, tag 3   (:1918-1922)
-            const int vu = s_hi_v + ((c << 2) + 2 - kScale);                  // up - 1, tag 2              (:1924)
-            const int vl = s_lo_v + ((c << 2) + 1 - kScale);                  // left - 1, tag 1            (:1923)
-            const int m1 = vd > vu ? vd : vu;
-            const int v0 = m1 > vl ? m1 : vl;                                 // v_max3_i32: value, cell, winning tag
-            kmax = kmax > v0 ? kmax : v0;
-            tags = __builtin_amdgcn_alignbit((unsigned)v0, tags, 2);          // (tags >> 2) | (tag << 30)
-            sp_next[c] = s_lo_v;
-            cur[c] = v0;                                  // (tagged until the X-drop pass below cleans it)
-            s_lo_v = s_hi_v;
+            for (int k = NV - 1; k >= 0; --k) tags = (tags << 2) | (v[k] & 0x00030003u);      // cell k at bits 2k, cell k + NV at 16 + 2k
         }
-        sp_next[C] = s_lo_v;
-        }
+        const unsigned k_lo = kmax2 & 0xFFFFu, k_hi = kmax2 >> 16;
+        int kmax = (int)(k_lo > k_hi ? k_lo : k_hi) + lane_base;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) cur[k] = (int)v[k];                  // (tagged until the X-drop pass below cleans it)
         kmax = group_max(kmax);
-        int round_best;
-        if constexpr (PK) {
-            // stored values are offset: true = stored + off.  A candidate derived from live cells is >= kPkFloor - 2 >= 4, one
-            // derived only from dropped cells (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
-            --off;
-            const int stored = kmax >> 7, band_best = stored + off;
-            round_best = stored > 3 && band_best > 0 ? band_best : 0;
-        } else {
-            const int band_best = kmax >> 7;              // arithmetic shift: the value part of the winner
-            round_best = band_best > 0 ? band_best : 0;
-        }
+        // stored values are offset: true = stored + off.  A candidate derived from live cells is >= kPkFloor - 2 >= 4, one
+        // derived only from dropped cells (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
+        --off;
+        const int stored = kmax >> 7, band_best = stored + off;
+        const int round_best = stored > 3 && band_best > 0 ? band_best : 0;
         const bool improved = alive && round_best > best; // :1933-1936
         const int imask = keep_opaque(improved ? -1 : 0);
         best = pick(imask, round_best, best);
@@ -596,28 +562,15 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
         best_top = pick(imask, pos_y, best_top);
         const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941, and "0 means dropped"
-        if constexpr (PK) {
-            const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);     // v_mul_u32_u24, full rate
+        const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);     // v_mul_u32_u24, full rate
 #pragma unroll
-            for (int k = 0; k < NV; ++k)                  // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
-                cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
-            if (C == 8) {
-                my_stage0[8 * (round & 15)] = (uint8_t)tags;
-                my_stage0[8 * (round & 15) + 1] = (uint8_t)(tags >> 16);
-            } else {
-                *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
-            }
+        for (int k = 0; k < NV; ++k)                  // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
+            cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+        if (C == 8) {
+            my_stage0[8 * (round & 15)] = (uint8_t)tags;
+            my_stage0[8 * (round & 15) + 1] = (uint8_t)(tags >> 16);
         } else {
-        const int thr = thr_true * kScale;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            // sub, shift, v_bitop3_b32 (0xA8 = (a | b) & c), all full rate; opaque, or hipcc turns it back into a half-rate
-            // v_cmp + v_cndmask pair.  Dropped -> kDropped, live -> cell index and tag stripped.
-            const int below_thr = keep_opaque(cur[c] - thr) >> 31;   // (opaque difference: `(a - b) >> 31` alone becomes cmp + select)
-            cur[c] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[c], (unsigned)below_thr, (unsigned)clean_mask, 0xA8);
-        }
-        if (C == 8) *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15)) = (uint16_t)(tags >> 16);
-        else        *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
+            *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
         }
         if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
             flush_codes(round >> 4);
@@ -626,17 +579,15 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
                 if (real && is_first) *my_dirs = dir_word;
                 my_dirs += n;
             }
-            if constexpr (PK) {
-                // re-base: the threshold (which climbs by one or two a round in stored terms) goes back to kPkFloor; dropped
-                // cells stay 0 (saturating), live ones -- this round's and the view of the round before -- are well above
-                const int delta = (thr_true - off) - kPkFloor;
-                const unsigned d2 = __umul24((unsigned)delta, (unsigned)kScale * 0x10001u);
+            // re-base: the threshold (which climbs by one or two a round in stored terms) goes back to kPkFloor; dropped
+            // cells stay 0 (saturating), live ones -- this round's and the view of the round before -- are well above
+            const int delta = (thr_true - off) - kPkFloor;
+            const unsigned d2 = __umul24((unsigned)delta, (unsigned)kScale * 0x10001u);
 #pragma unroll
-                for (int k = 0; k < NV; ++k) cur[k] = (int)sg_pk_sub_sat((unsigned)cur[k], d2);
+            for (int k = 0; k < NV; ++k) cur[k] = (int)sg_pk_sub_sat((unsigned)cur[k], d2);
 #pragma unroll
-                for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
-                off += delta;
-            }
+            for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
+            off += delta;
         }
         alive = alive && round_best != 0;                 // :1943-1946
         last_round = round;
@@ -654,6 +605,243 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     // .z: the best cell's band lane, and bit 8 = "code records in tag format" (cell k at bits 2k: 3 diag, 2 up, 1 left)
     if (real && is_first) {
+        if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
+        summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
+    }
+}
+
+// ---- sweep, ONE lane per alignment (the whole band in 16 registers of two cells): the largest batches ---------------
+//
+// The cell of the split sweep above with G = 1: 64 alignments per wavefront and nothing crosses lanes -- the band's end
+// cells, its neighbours, both character streams and the band maximum are the lane's own.  What a round costs besides the
+// cells (direction, windows, match bits, best / threshold bookkeeping: ~80 instructions) is paid once per 64 alignments
+// instead of once per 32, so a batch that still gives every SIMD two or more of these wavefronts runs a third faster.
+// Register k = cells k (low half) and k + 16 (high half); the windows are 2 x 64 bits per sequence.
+
+// One sequence's character stream of one alignment (the format sg_pack_streams_kernel writes), read 16 characters ahead:
+//   sreg   the next 16 characters (the next one at bit used4), pend: the characters after those (p_fill of them, low-aligned,
+//   zeros above), ahead: the word after pend (a load issued at the previous top-up), w_next: index of the word after `ahead`.
+// top_up() runs every 16 rounds -- a stream gives at most 16 characters in 16 rounds -- so the round itself holds no load.
+struct SgStream {
+    const unsigned long long *words;                      // word w of the stream at words[w * stride]
+    unsigned long long sreg, pend, ahead;
+    int p_fill, w_next, used4;
+    __device__ __forceinline__ void start(const unsigned long long *w, size_t stride, int first_char)
+    {
+        words = w;
+        const int c0 = first_char & 15, w0i = first_char >> 4;
+        const unsigned long long w0 = words[w0i * stride], w1 = words[(w0i + 1) * stride];
+        sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
+        pend = w1 >> (4 * c0);
+        p_fill = 16 - c0;
+        ahead = words[(w0i + 2) * stride];
+        w_next = w0i + 3;
+        used4 = 0;
+    }
+    __device__ __forceinline__ unsigned next() const { return (unsigned)(sreg >> used4) & 15u; }
+    __device__ __forceinline__ void top_up(size_t stride)
+    {
+        const int k = used4 >> 2;
+        sreg = k < 16 ? sreg >> used4 : 0ull;
+        used4 = 0;
+        const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
+        const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;           // pend's characters behind the 16 - k left
+        const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
+        sreg |= add_p | add_a;
+        if (rem > 0 || from_pend == p_fill) {                                       // pend is used up: `ahead` becomes pend
+            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
+            p_fill = 16 - rem;
+            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;         // a band that has left the matrix keeps stepping
+            ahead = words[(size_t)w * stride];
+            ++w_next;
+        } else {
+            pend = from_pend ? pend >> (4 * from_pend) : pend;
+            p_fill -= from_pend;
+        }
+    }
+};
+
+template <int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
+sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
+                       uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
+{
+    constexpr int NV = 16, A = 64;
+    __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]: one 128-byte line each per flush
+    const int lane = threadIdx.x;
+    const uint32_t block_first = blockIdx.x * A;
+    const uint32_t a0 = block_first + lane;
+    const bool real = a0 < n;
+    const uint32_t a = real ? a0 : n - 1;
+    constexpr size_t kStreamStride = 2 * A;
+    const unsigned long long *stream_a = streams + (size_t)blockIdx.x * kStreamWords * kStreamStride + 2 * lane;
+    uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
+    auto flush_codes = [&](int g16) {                     // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < A / 8; ++q) {                 // 8 alignments x 128 B per store instruction
+            const int fa = q * 8 + (lane >> 3), part = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
+            if (block_first + fa < n)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + block_first + fa) * kCodeWindow + 2 * part) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto pick = [](int m, unsigned if_set, unsigned if_clear) { return __builtin_amdgcn_bitop3_b32((unsigned)m, if_set, if_clear, 0xCA); };
+
+    sg_keep_f16_denormals();
+    unsigned cur[NV], sp_a[NV + 1], sp_b[NV + 1];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) cur[k] = 0;
+#pragma unroll
+    for (int k = 0; k <= NV; ++k) sp_a[k] = sp_b[k] = 0;
+    cur[NV - 1] = (unsigned)((kXDrop - kPkBase0) * kScale) << 16;             // band cell 31
+    int off = kPkBase0;                                   // true value = stored value + off (off = base - round)
+    // round 0: cell c sits at row 31 - c (valid for c <= 30), column c - 31 (never valid); windows: cell c <-> field c & 15 of word c / 16
+    unsigned long long aw0 = 0, aw1 = 0, bw0 = kPadSeq2 * 0x1111111111111111ull, bw1 = bw0;
+    {
+        const unsigned long long w0 = stream_a[0], w1 = stream_a[kStreamStride];   // seq1[0..31]
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int i1 = 30 - c;
+            const unsigned long long ch = i1 >= 0 ? (((i1 & 16) ? w1 : w0) >> (4 * (i1 & 15))) & 15ull : (unsigned long long)kPadSeq1;
+            if (c < 16) aw0 |= ch << (4 * c);
+            else        aw1 |= ch << (4 * (c - 16));
+        }
+    }
+    SgStream sa, sb;                                      // seq1 is consumed when the band steps down, seq2 when it steps right
+    sa.start(stream_a, kStreamStride, 31);
+    sb.start(stream_a + 1, kStreamStride, 0);
+    int pos_x = 31;
+    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
+    bool alive = true;
+    unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
+    stage_codes[lane][0] = make_uint2(0, 0);
+
+    auto one_round = [&](const int round, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
+        const bool right = (cur[0] & 0xFFFFu) < (cur[NV - 1] >> 16);          // source.cpp:1895: band cell 0 against band cell 31
+        const int rmask = keep_opaque(right ? -1 : 0);
+        const unsigned rm = (unsigned)rmask, dm = ~rm;
+        pos_x -= rmask;
+        dir_word = __builtin_amdgcn_alignbit(rm, dir_word, 1);
+        const int pos_y = round - (pos_x - 31);
+        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
+        // the windows follow the band: seq1's moves up one field on a step down, seq2's down one field on a step right
+        {
+            const unsigned a_in = sa.next(), b_in = sb.next();
+            const unsigned shift_a = 4u & dm, shift_b = 4u & rm;
+            const unsigned a_carry = (unsigned)(aw0 >> 60) & dm, b_carry = (unsigned)bw1 & 15u & rm;
+            aw1 = (aw1 << shift_a) | a_carry;
+            aw0 = (aw0 << shift_a) | (a_in & dm);
+            bw0 = (bw0 >> shift_b) | ((unsigned long long)b_carry << 60);
+            bw1 = (bw1 >> shift_b) | ((unsigned long long)(b_in & rm) << 60);
+            sa.used4 += 4 & dm;
+            sb.used4 += 4 & rm;
+        }
+        // bit 4c of a word clear: its cell c is a match (three-bit codes: bit 0 of z | z >> 1 | z >> 2 = "they differ")
+        const unsigned long long z0 = aw0 ^ bw0, z1 = aw1 ^ bw1;
+        const unsigned long long d0 = z0 | (z0 >> 1) | (z0 >> 2), d1 = z1 | (z1 >> 1) | (z1 >> 2);
+        const unsigned dw[4] = {(unsigned)d0, (unsigned)(d0 >> 32), (unsigned)d1, (unsigned)(d1 >> 32)};        // cells 8w .. 8w + 7
+        constexpr unsigned kByteOnes = 0x01010101u;
+        unsigned even[4], odd[4];                         // bit 0 of byte j = cell 8w + 2j / 8w + 2j + 1 matches
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            even[w] = ~dw[w] & kByteOnes;
+            odd[w] = ~(dw[w] >> 4) & kByteOnes;
+        }
+        // S of cells (k, k + 16), k = 0 .. 16: left of register k is sv[k], up is sv[k + 1]; past the band's ends: dropped (0)
+        unsigned sv[NV + 1];
+        sv[0] = pick(rmask, cur[0], cur[NV - 1] << 16);                       // (cell -1, cell 15)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sv[k + 1] = pick(rmask, k + 1 < NV ? cur[k + 1] : cur[0] >> 16 /* (cell 16, cell 32) */, cur[k]);
+        auto both = [](int k) { return (unsigned)(k << 2) | ((unsigned)((k + NV) << 2) << 16); };   // the two cell indices
+        unsigned vl[NV], vu[NV], v[NV];
+#pragma unroll
+        for (int m = 0; m < NV / 2; ++m) {                // two registers per v_lshl_add_u64 (no half ever carries)
+            const unsigned long long pair = (unsigned long long)sv[2 * m] | ((unsigned long long)sv[2 * m + 1] << 32);
+            const unsigned long long l = pair + (((unsigned long long)(both(2 * m + 1) + 0x00010001u) << 32) | (both(2 * m) + 0x00010001u));
+            vl[2 * m] = (unsigned)l;
+            vl[2 * m + 1] = (unsigned)(l >> 32);
+            if (m > 0) {
+                const unsigned long long u = pair + (((unsigned long long)(both(2 * m) + 0x00020002u) << 32) | (both(2 * m - 1) + 0x00020002u));
+                vu[2 * m - 1] = (unsigned)u;
+                vu[2 * m] = (unsigned)(u >> 32);
+            }
+        }
+        vu[0] = sv[1] + (both(0) + 0x00020002u);
+        vu[NV - 1] = sv[NV] + (both(NV - 1) + 0x00020002u);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const unsigned dsel = pick(rmask, sp[k + 1], sp[k]);              // diagonal (:1897 / :1908)
+            const unsigned j = (unsigned)(k & 7) >> 1;    // cell k = byte j of word k / 8, cell k + 16 = byte j of word k / 8 + 2
+            const unsigned sel = 0x000C000Cu | (j << 8) | ((4u + j) << 24);
+            const unsigned f = __builtin_amdgcn_perm(k & 1 ? odd[(k >> 3) + 2] : even[(k >> 3) + 2], k & 1 ? odd[k >> 3] : even[k >> 3], sel);
+            const unsigned vd = dsel + f + (both(k) + 0x00030003u + (unsigned)kScale * 0x10001u);     // dia + 3 / dia + 1, tag 3
+            v[k] = sg_pk_max3(vd, vu[k], vl[k]);
+            sp_next[k] = sv[k];
+        }
+        sp_next[NV] = sv[NV];
+        const unsigned kmax2 = sg_pk_max3(sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), sg_pk_max3(v[3], v[4], v[5]), sg_pk_max3(v[6], v[7], v[8])),
+                                          sg_pk_max3(sg_pk_max3(v[9], v[10], v[11]), sg_pk_max3(v[12], v[13], v[14]), v[15]), v[15]);
+        // tags: the low bytes of registers k and k + 4 (k + 8 and k + 12) gathered as (cell k, k + 4, k + 16, k + 20), masked and
+        // shifted together: byte j of the two accumulators = four consecutive cells; two more gathers sort the bytes
+        unsigned acc_a = 0, acc_b = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            acc_a = (acc_a << 2) | (__builtin_amdgcn_perm(v[k + 4], v[k], 0x06020400u) & 0x03030303u);
+            acc_b = (acc_b << 2) | (__builtin_amdgcn_perm(v[k + 12], v[k + 8], 0x06020400u) & 0x03030303u);
+        }
+        const unsigned tags_lo = __builtin_amdgcn_perm(acc_b, acc_a, 0x05040100u);       // cells 0 .. 15, cell c at bits 2c
+        const unsigned tags_hi = __builtin_amdgcn_perm(acc_b, acc_a, 0x07060302u);       // cells 16 .. 31
+        const unsigned k_lo = kmax2 & 0xFFFFu, k_hi = kmax2 >> 16;
+        const int kmax = (int)(k_lo > k_hi ? k_lo : k_hi);
+        // true = stored + off; a candidate derived from live cells is >= kPkFloor - 2 >= 4, one derived only from dropped cells
+        // (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
+        --off;
+        const int stored = kmax >> 7, band_best = stored + off;
+        const int round_best = stored > 3 && band_best > 0 ? band_best : 0;
+        const bool improved = alive && round_best > best;                     // :1933-1936
+        const int imask = keep_opaque(improved ? -1 : 0);
+        best = (int)pick(imask, (unsigned)round_best, (unsigned)best);
+        best_round = (int)pick(imask, (unsigned)round, (unsigned)best_round);
+        best_lane = (int)pick(imask, (unsigned)(kmax >> 2) & 31u, (unsigned)best_lane);  // highest cell among equals (:1957)
+        best_top = (int)pick(imask, (unsigned)pos_y, (unsigned)best_top);
+        const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941
+        const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);
+#pragma unroll
+        for (int k = 0; k < NV; ++k)                      // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
+            cur[k] = __builtin_amdgcn_bitop3_b32(v[k], sg_pk_below(v[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+        stage_codes[lane][round & 15] = make_uint2(tags_lo, tags_hi);
+        if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
+            flush_codes(round >> 4);
+            sa.top_up(kStreamStride);
+            sb.top_up(kStreamStride);
+            if ((round & 31) == 31) {
+                if (real) *my_dirs = dir_word;
+                my_dirs += n;
+            }
+            // re-base: the threshold goes back to kPkFloor (see the split sweep)
+            const int delta = (thr_true - off) - kPkFloor;
+            const unsigned d2 = __umul24((unsigned)delta, (unsigned)kScale * 0x10001u);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) cur[k] = sg_pk_sub_sat(cur[k], d2);
+#pragma unroll
+            for (int k = 0; k <= NV; ++k) sp_next[k] = sg_pk_sub_sat(sp_next[k], d2);
+            off += delta;
+        }
+        alive = alive && round_best != 0;                 // :1943-1946
+        last_round = round;
+    };
+
+    for (int round = 1; round < kMaxRound; round += 2) {  // (the exit test once per 16 rounds: see the split sweep)
+        if ((round & 15) == 1 && !__any(alive)) break;
+        one_round(round, sp_a, sp_b);
+        one_round(round + 1, sp_b, sp_a);
+    }
+    if ((last_round & 15) != 15) flush_codes(last_round >> 4);
+    if (real) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
         summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
     }
@@ -1001,7 +1189,7 @@ inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeWindows * 
 inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * sizeof(uint32_t)); }
 }  // namespace
 
-inline size_t streams_bytes(size_t n) { return round16(((n + 31) / 32 * 32) * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }   // whole blocks of 32 / 16
+inline size_t streams_bytes(size_t n) { return round16(((n + 63) / 64 * 64) * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }   // whole blocks of 64 / 32 / 16
 inline size_t moves_bytes(size_t n) { return round16(n * (size_t)kMoveWords * sizeof(unsigned long long)); }
 
 size_t semiglobal_workspace_bytes(size_t n)
@@ -1010,36 +1198,33 @@ size_t semiglobal_workspace_bytes(size_t n)
 }
 
 namespace {
-// Which sweep a batch of n alignments runs: 0 / 100 + W = band per half-wavefront (one cell per lane: low latency, fills
-// the chip from a few thousand alignments); 10 * G + W = band split over G lanes (8 / 16 cells per lane: far fewer
-// instructions per alignment, 16 / 32 alignments per wavefront), compiled for W resident wavefronts per SIMD.
-// SWMI_SG_SWEEP forces one: 0, G or 10 * G + W.  The split kernels are compiled once per scheduling target W
-// (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per SIMD, and the version whose W matches what
-// the batch actually puts on a SIMD wins by 20-30 % (profiles/r01_sg_kernel_matrix.txt).
+// Which sweep a batch of n alignments runs: 0 / 100 + W = band per half-wavefront (one cell per lane, sg_forward_kernel: kept
+// for comparison, no batch size picks it any more); 10 * G + W = band over G lanes (G = 4, 2: sg_forward_split_kernel, 8 / 16
+// cells per lane, 16 / 32 alignments per wavefront; G = 1: sg_forward_lane_kernel, 64 per wavefront), compiled for W
+// resident wavefronts per SIMD.  swmi_semiglobal_set_mapping / SWMI_SG_SWEEP force one: 0, G or 10 * G + W.  The kernels
+// are compiled once per scheduling target W (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per
+// SIMD, and the version whose W matches what the batch actually puts on a SIMD wins by 20-40 %.
 int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
 {
-    int sweep = 0;
     if (tuning.force_sweep >= 0) {
-        sweep = tuning.force_sweep;
-        if (sweep == 4) sweep = 44;
-        if (sweep == 2) sweep = 24;
-    } else if (n >= kSplit4MinBatch) {
-        // wavefronts per SIMD the batch yields with 4 / 2 lanes per alignment on THIS device (4 SIMDs per CU; a partitioned
-        // gfx950 reports fewer CUs), and the sweep times measured for them on 256 CUs (ms; both mappings take a fixed time
-        // per started wavefront-per-SIMD, so the model carries over to other CU counts through w4 / w2)
-        const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
-        const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds);
-        // (profiles/r02_sg_kernel_matrix.txt)
-        const double t4 = w4 <= 1 ? 12.9 : w4 == 2 ? 19.2 : w4 == 3 ? 27.0 : w4 == 4 ? 34.3 : 4.5 + 7.45 * w4;
-        const double t2 = w2 <= 1 ? 19.6 : w2 == 2 ? 30.9 : w2 == 3 ? 43.7 : 5.4 + 12.85 * w2;
-        // the build whose scheduling target equals the wavefronts a SIMD actually gets wins (W = 3 stays the fastest
-        // 2-lane build beyond 3 per SIMD)
-        sweep = t4 <= t2 ? 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4) : 20 + (w2 < 1 ? 1 : w2 > 3 ? 3 : w2);
+        const int s = tuning.force_sweep;
+        return s == 4 ? 44 : s == 2 ? 24 : s == 1 ? 13 : s;
     }
-    return sweep;
+    // wavefronts per SIMD the batch yields with 4 / 2 / 1 lanes per alignment on THIS device (4 SIMDs per CU; a partitioned
+    // gfx950 reports fewer CUs).  Each mapping takes a fixed time per started wavefront-per-SIMD, measured on 256 CUs
+    // (profiles/r03_sg_kernel_matrix.txt, ms): fewer lanes per alignment = fewer instructions per alignment, but a SIMD
+    // with a single wavefront issues an instruction every ~6 cycles instead of every ~4.3.
+    const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
+    const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds), w1 = (int)((n / 64 + simds - 1) / simds);
+    const double t4 = 3.6 + 6.2 * (w4 < 1 ? 1 : w4), t2 = 3.6 + 9.0 * (w2 < 1 ? 1 : w2), t1 = w1 <= 1 ? 21.0 : 3.7 + 16.05 * w1;
+    // the build whose scheduling target equals the wavefronts a SIMD actually gets (at most 4; the lane kernel's 145 registers
+    // fit three per SIMD)
+    if (t4 <= t2 && t4 <= t1) return 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4);
+    if (t2 <= t1) return 20 + (w2 < 1 ? 1 : w2 > 4 ? 4 : w2);
+    return 10 + (w1 < 1 ? 1 : w1 > 3 ? 3 : w1);
 }
-// 200 + 10 G + W: the PK form (two cells per register) of the split sweep
-inline bool sweep_is_split(int sweep) { return (sweep >= 21 && sweep <= 44) || (sweep >= 221 && sweep <= 244); }
+inline bool sweep_is_split(int sweep) { return sweep >= 11 && sweep <= 44; }            // packed tag records (every mapping but the half-wavefront one)
+inline int sweep_lanes(int sweep) { return sweep / 10; }
 bool choose_lane_traceback(size_t n, const SgTuning &tuning)
 {
     return tuning.force_traceback >= 0 ? tuning.force_traceback == 1 : n >= kLaneTracebackMinBatch;
@@ -1051,8 +1236,10 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
 {
     const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep_name && sweep_len) {
-        if (sweep_is_split(sweep))
-            snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d, %s>", sweep % 100 / 10, sweep % 10, sweep > 200 ? "true" : "false");
+        if (sweep_is_split(sweep) && sweep_lanes(sweep) == 1)
+            snprintf(sweep_name, sweep_len, "sg_forward_lane_kernel<%d>", sweep % 10);
+        else if (sweep_is_split(sweep))
+            snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep_lanes(sweep), sweep % 10);
         else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
     }
     if (tb_name && tb_len)
@@ -1076,33 +1263,32 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep_is_split(sweep)) {
-        const uint32_t per_block = sweep % 100 / 10 == 4 ? 16 : 32;         // alignments per sweep wavefront: 64 / G
+        const uint32_t per_block = 64 / sweep_lanes(sweep);                 // alignments per sweep wavefront: 64 / G
         const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
                            (uint32_t)n, streams, per_block);
-        const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32));
-#define SWMI_SG_LAUNCH(G, W, PK, GRID) \
-    hipLaunchKernelGGL((sg_forward_split_kernel<G, W, PK>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+        const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32)), grid1((unsigned)((n + 63) / 64));
+#define SWMI_SG_LAUNCH1(W) \
+    hipLaunchKernelGGL((sg_forward_lane_kernel<W>), grid1, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+#define SWMI_SG_LAUNCH(G, W, GRID) \
+    hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
         switch (sweep) {
-        case 41: SWMI_SG_LAUNCH(4, 1, false, grid4); break;
-        case 42: SWMI_SG_LAUNCH(4, 2, false, grid4); break;
-        case 43: SWMI_SG_LAUNCH(4, 3, false, grid4); break;
-        case 44: SWMI_SG_LAUNCH(4, 4, false, grid4); break;
-        case 21: SWMI_SG_LAUNCH(2, 1, false, grid2); break;
-        case 22: SWMI_SG_LAUNCH(2, 2, false, grid2); break;
-        case 23: SWMI_SG_LAUNCH(2, 3, false, grid2); break;
-        case 24: SWMI_SG_LAUNCH(2, 4, false, grid2); break;
-        case 241: SWMI_SG_LAUNCH(4, 1, true, grid4); break;
-        case 242: SWMI_SG_LAUNCH(4, 2, true, grid4); break;
-        case 243: SWMI_SG_LAUNCH(4, 3, true, grid4); break;
-        case 244: SWMI_SG_LAUNCH(4, 4, true, grid4); break;
-        case 221: SWMI_SG_LAUNCH(2, 1, true, grid2); break;
-        case 222: SWMI_SG_LAUNCH(2, 2, true, grid2); break;
-        case 223: SWMI_SG_LAUNCH(2, 3, true, grid2); break;
-        case 224: SWMI_SG_LAUNCH(2, 4, true, grid2); break;
+        case 41: SWMI_SG_LAUNCH(4, 1, grid4); break;
+        case 42: SWMI_SG_LAUNCH(4, 2, grid4); break;
+        case 43: SWMI_SG_LAUNCH(4, 3, grid4); break;
+        case 44: SWMI_SG_LAUNCH(4, 4, grid4); break;
+        case 21: SWMI_SG_LAUNCH(2, 1, grid2); break;
+        case 22: SWMI_SG_LAUNCH(2, 2, grid2); break;
+        case 23: SWMI_SG_LAUNCH(2, 3, grid2); break;
+        case 24: SWMI_SG_LAUNCH(2, 4, grid2); break;
+        case 11: SWMI_SG_LAUNCH1(1); break;
+        case 12: SWMI_SG_LAUNCH1(2); break;
+        case 13: SWMI_SG_LAUNCH1(3); break;
+        case 14: SWMI_SG_LAUNCH1(4); break;
         default: return hipErrorInvalidValue;
         }
 #undef SWMI_SG_LAUNCH
+#undef SWMI_SG_LAUNCH1
     } else {
         const unsigned waves = (unsigned)((n + 1) / 2);
         const dim3 grid((waves + 3) / 4);

@@ -847,11 +847,10 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
 
 int swmi_semiglobal_set_mapping(int sweep, int traceback)
 {
-    const bool sweep_ok = sweep == -1 || sweep == 0 || sweep == 2 || sweep == 4 || (sweep >= 21 && sweep <= 24) ||
-                          (sweep >= 41 && sweep <= 44) || (sweep >= 101 && sweep <= 103) || (sweep >= 221 && sweep <= 224) ||
-                          (sweep >= 241 && sweep <= 244);
+    const bool sweep_ok = sweep == -1 || sweep == 0 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 14) ||
+                          (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44) || (sweep >= 101 && sweep <= 103);
     if (!sweep_ok || traceback < -1 || traceback > 1)
-        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 0, 2, 4, 21..24, 41..44, 101..103, 221..224 or 241..244, traceback -1, 0 or 1",
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 0, 1, 2, 4, 11..14, 21..24, 41..44 or 101..103, traceback -1, 0 or 1",
                     sweep, traceback);
     sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)) | (uint64_t(uint32_t(traceback + 1)) << 32));
     return SWMI_OK;
