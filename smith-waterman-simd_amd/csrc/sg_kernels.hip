@@ -4,8 +4,8 @@
 //
 // Not a translation of the AVX2 variants (one 32-byte vector per anti-diagonal, u8 cells re-based every round,
 // source.cpp:2099-2109).  Here:
-//   * forward sweep: the 32 cells of the band (BANDWIDTH, source.cpp:1848) live in 32 lanes (sg_forward_kernel, small
-//     batches) or in 4 / 2 lanes with 8 / 16 cells each (sg_forward_split_kernel, large batches); cell values stay int32.
+//   * forward sweep: the 32 cells of the band (BANDWIDTH, source.cpp:1848) live in 4 / 2 lanes with 8 / 16 cells each
+//     (sg_forward_split_kernel) or in one lane (sg_forward_lane_kernel, the largest batches), two 16-bit cells per register.
 //     The band's direction (right / down) is decided per alignment every round from its two end cells (:1895).  Instead
 //     of the reference's 4 MB table of cell values per alignment (source.cpp:1876) the sweep stores, per round, only what
 //     the traceback needs: a 2-bit predecessor TAG per cell (3 diagonal / 2 up / 1 left: the candidate that won the cell's
@@ -47,16 +47,11 @@ constexpr size_t kLaneTracebackMinBatch = 2048;  // one lane per walk (+ expand 
 
 // Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
 // three-way max: 3 diagonal, 2 up, 1 left (0: round 0 / nothing) -- the reference's tie-break order (source.cpp:1962-1971)
-// falls out of comparing equal values by tag.  The half-wavefront sweep stores them as two 32-bit words per round (bit k
-// of word 0 / word 1 = low / high tag bit of band cell k: the two ballots as they come), the split sweep packed, band
-// cell k at bits 2k..2k+1 of the round's 64 bits; summary[a].z = band lane of the best cell | kTagFormat says which.
+// falls out of comparing equal values by tag -- band cell k at bits 2k..2k+1 of the round's 64 bits.
 // The traceback's move code: 1 diagonal, 2 up, 3 left = (4 - tag) & 3.
-constexpr int kTagFormat = 1 << 8;
-__device__ __forceinline__ unsigned decode_code(uint2 cw, int bl, bool packed_tags)
+__device__ __forceinline__ unsigned record_tag(uint2 cw, int bl)
 {
-    const unsigned from_words = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
-    const unsigned from_packed = ((bl & 16 ? cw.y : cw.x) >> (2 * (bl & 15))) & 3u;
-    return (4u - (packed_tags ? from_packed : from_words)) & 3u;
+    return (unsigned)((((unsigned long long)cw.y << 32) | cw.x) >> (2 * bl)) & 3u;
 }
 
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
@@ -70,128 +65,18 @@ __device__ __forceinline__ int row16_max(int v)
     return v;
 }
 
-__device__ __forceinline__ int sat_dec(int v)             // max(v - 1, 0) for v >= 0: v_sub_u32 ... clamp
-{
-    return (int)__builtin_elementwise_sub_sat((unsigned)v, 1u);
-}
-
 __device__ __forceinline__ int keep_opaque(int v)         // stops hipcc from turning `x & mask` into a v_cndmask
 {
     asm volatile("" : "+v"(v));
     return v;
 }
 
-// Sweep for small batches: one band cell per lane, two alignments per wavefront.
-// codes[code_index(n, a, r)] = the round's two tag words (above); dirs = the band's move bits (above);
-// summary[a] = {score, best_round, best_lane (| kTagFormat), row of the band's top cell in best_round}
-//
-// A round is one long dependency chain, and with one wavefront per SIMD or fewer (what a small batch gives) EVERY
-// instruction, vector or scalar, costs the wavefront ~5 cycles -- and a v_cndmask_b32 that takes its mask from VCC costs 23
-// (profiles/r02_microbench_valu_rate5.txt).  So the round is written for instruction COUNT: the cell is the tagged
-// v_max3 of the split sweep below (value * 128 + cell * 4 + tag: the winner's tag IS the predecessor code, the band maximum
-// needs no key and no ballot + count-leading-zeros to find the cell), selects are v_bitop3 with all-ones / all-zeros
-// masks, and every cross-lane step is a DPP move or a v_readlane (an LDS-crossbar shuffle costs more than all of a
-// round's arithmetic).  ~95 instructions per round (round 1's formulation: ~128).
+// A cell value of the sweeps travels as  stored * kScale + band_cell * 4 + tag  in 16 bits, stored = true + round - base (a gap
+// or a mismatch step then adds 0 / 1 and a match 3: nothing negative is ever added to an unsigned half), re-based every 16
+// rounds so that the X-drop threshold is kPkFloor again; kPkBase0 = the base before round 1 (threshold 1 + 1 - base = kPkFloor).
 constexpr int kScale = 128;
-// The split and lane sweeps store a cell's value as  true + round - base  (a gap or a mismatch step then adds 0 / 1 and a
-// match 3: nothing negative is ever added to an unsigned half), re-based every 16 rounds so that the X-drop threshold is
-// kPkFloor again; kPkBase0 = the base before round 1 (threshold 1 + 1 - base = kPkFloor).
 constexpr int kPkFloor = 8;
 constexpr int kPkBase0 = 2 - kPkFloor;
-
-template <int W>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
-sg_forward_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
-                  uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
-{
-    const int lane = threadIdx.x & 63;
-    const int k = lane & 31;                              // lane of the band, as the reference numbers them
-    const bool second = lane >= 32;                       // which of the wavefront's two alignments
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    uint32_t a = wave * 2 + (second ? 1u : 0u);
-    if (wave * 2 >= n) return;
-    const bool real = a < n;
-    if (!real) a = n - 1;                                 // odd tail: shadow the last alignment, store nothing
-    const uint32_t seq_base = a * (uint32_t)kLen;         // n <= 2^18 alignments per launch: fits 32 bits
-    uint2 *all_codes = reinterpret_cast<uint2 *>(codes);
-    uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
-    const bool writer = real && k == 0;
-    auto pick = [](int m, int if_set, int if_clear) { return (int)__builtin_amdgcn_bitop3_b32((unsigned)m, (unsigned)if_set, (unsigned)if_clear, 0xCA); };
-    constexpr int kDropped = -kScale;                     // value -1: every candidate derived from it is <= 0 and dropped again
-    const int first_mask = keep_opaque(k == 0 ? -1 : 0), last_mask = keep_opaque(k == 31 ? -1 : 0);
-    const int second_mask = keep_opaque(second ? -1 : 0);
-    // per-candidate constants: cell index and tag in the low 7 bits, the -1 of a gap move / mismatch folded in
-    const int c_diag = (k << 2) + 3 - kScale, c_up = (k << 2) + 2 - kScale, c_left = (k << 2) + 1 - kScale;
-
-    int cur = k == 31 ? kXDrop * kScale : kDropped;       // clean (value * 128), as are hor / ver
-    int hor = kDropped, ver = kDropped;
-    int pos_x = 31;                                       // the reference's now_pos_x (31 leading pads); now_pos_y = round - (pos_x - 31)
-    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0;
-    bool alive = true;
-    unsigned dir_word = 0;                                // move bits of the current 32 rounds: round r enters at bit 31, ends at bit r & 31
-    if (writer) all_codes[code_index(n, a, 0)] = make_uint2(0, 0);
-
-    int round = 1;
-    for (; round < kMaxRound; ++round) {
-        if (!__any(alive)) break;
-        // direction of each alignment's band: lane 0 against lane 31 (source.cpp:1895)
-        const int ra = __builtin_amdgcn_readlane(cur, 0) < __builtin_amdgcn_readlane(cur, 31) ? -1 : 0;      // scalar masks
-        const int rb = __builtin_amdgcn_readlane(cur, 32) < __builtin_amdgcn_readlane(cur, 63) ? -1 : 0;
-        const int rmask = keep_opaque(pick(second_mask, rb, ra));
-        const int above_raw = __builtin_amdgcn_update_dpp(0, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);   // cur[k+1]
-        const int below_raw = __builtin_amdgcn_update_dpp(0, cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);   // cur[k-1]
-        const int from_above = pick(last_mask, kDropped, above_raw), from_below = pick(first_mask, kDropped, below_raw);
-        const int dia = pick(rmask, ver, hor);            // :1897 / :1908 (last round's up / left)
-        hor = pick(rmask, cur, from_below);               // left: :1898 / :1910-1911
-        ver = pick(rmask, from_above, cur);               // up:   :1899-1900 / :1909
-        pos_x -= rmask;
-        dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);
-        const int pos_y = round - (pos_x - 31);
-        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;         // :1903, :1913: checked before the round is stored
-        const int i1 = pos_y + 30 - k;                    // 0-based index into seq1 of this lane's row y = pos_y + 31 - k
-        const int i2 = pos_x - 63 + k;                    // 0-based index into seq2 of this lane's column x = pos_x - 62 + k
-        const unsigned l1 = seq1s[seq_base + (uint32_t)min(max(i1, 0), kLen - 1)];
-        const unsigned l2 = seq2s[seq_base + (uint32_t)min(max(i2, 0), kLen - 1)];
-        // a match needs both positions inside their sequences (pads never match, source.cpp:1861-1873) and a base < 4
-        // (:1918-1920): "i outside [0, kLen)" = sign bit of i | (kLen - 1 - i)
-        const unsigned outside = (unsigned)(i1 | (kLen - 1 - i1) | i2 | (kLen - 1 - i2)) >> 31;                // 0 / 1
-        const unsigned differ = (l1 ^ l2) | (l1 >> 2) | outside;                                                // 0 (a match) .. 255
-        const int f = (int)((differ - 1u) & (2u * kScale));   // 256 for a match, 0 otherwise: bit 8 of differ - 1 (no compare, no select)
-        const int vd = dia + f + c_diag;                  // dia + 1 / dia - 1, tag 3   (:1922)
-        const int vu = ver + c_up;                        // up - 1, tag 2              (:1924)
-        const int vl = hor + c_left;                      // left - 1, tag 1            (:1923)
-        const int m1 = vd > vu ? vd : vu;
-        const int v0 = m1 > vl ? m1 : vl;                 // v_max3_i32: value, cell, winning tag
-        const int rm = row16_max(v0);
-        const int kmax_a = max(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
-        const int kmax_b = max(__builtin_amdgcn_readlane(rm, 32), __builtin_amdgcn_readlane(rm, 48));
-        const int kmax = pick(second_mask, kmax_b, kmax_a);                    // value, then the highest cell among equals (:1957-1958)
-        const int band_best = kmax >> 7;
-        const int round_best = band_best > 0 ? band_best : 0;
-        const bool improved = alive && round_best > best; // :1933-1936
-        const int imask = keep_opaque(improved ? -1 : 0);
-        best = pick(imask, round_best, best);
-        best_round = pick(imask, round, best_round);
-        best_lane = pick(imask, (kmax >> 2) & 31, best_lane);
-        best_top = pick(imask, pos_y, best_top);
-        const int thr = (best - kXDrop > 1 ? best - kXDrop : 1) * kScale;      // :1938-1941, and "0 means dropped"
-        const int below_thr = keep_opaque(v0 - thr) >> 31;
-        cur = (int)__builtin_amdgcn_bitop3_b32((unsigned)v0, (unsigned)below_thr, (unsigned)~(kScale - 1), 0xA8);   // (v0 | dropped) & clean
-        // the winners' tags, as two ballots: word 0 = low tag bits, word 1 = high tag bits of the 32 band cells
-        const unsigned long long t0 = __ballot((v0 & 1) != 0), t1 = __ballot((v0 & 2) != 0);
-        if (writer) all_codes[code_index(n, a, round)] = second ? make_uint2((unsigned)(t0 >> 32), (unsigned)(t1 >> 32)) : make_uint2((unsigned)t0, (unsigned)t1);
-        if ((round & 31) == 31) {                         // (a running pointer: `(round >> 5) * n` would be recomputed every round)
-            if (writer) *my_dirs = dir_word;
-            my_dirs += n;
-        }
-        alive = alive && round_best != 0;                 // :1943-1946
-    }
-    const int last_round = round - 1;                     // the last round that ran
-    if (writer) {
-        if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
-        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
-    }
-}
 
 // ---- character streams for the split sweep -------------------------------------------------------------------------
 //
@@ -603,10 +488,9 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         one_round(round + 1, sp_b, sp_a);
     }
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
-    // .z: the best cell's band lane, and bit 8 = "code records in tag format" (cell k at bits 2k: 3 diag, 2 up, 1 left)
     if (real && is_first) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
-        summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
+        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
     }
 }
 
@@ -843,7 +727,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     if (real) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
-        summary[a] = make_int4(best - kXDrop, best_round, best_lane | kTagFormat, best_top);
+        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
     }
 }
 
@@ -862,8 +746,6 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     const uint2 *all_codes = reinterpret_cast<const uint2 *>(codes);
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]
     int4 sum = summary[a];
-    const bool tag_format = (sum.z & kTagFormat) != 0;      // packed tags (split sweep) / two tag words (half-wavefront sweep)
-    sum.z &= 31;
     const int y0 = sum.w + 31 - sum.z;                    // .w = row of the band's top cell in the best round
     const int x0 = sum.y - y0;
     int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
@@ -913,7 +795,7 @@ sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
                 const unsigned lo = __builtin_amdgcn_readlane(cw.x, idx), hi = __builtin_amdgcn_readlane(cw.y, idx);
                 const int top = __builtin_amdgcn_readlane(tw, idx);
                 const int bl = 31 - (y - top);
-                const int code = (int)decode_code(make_uint2(lo, hi), bl, tag_format);
+                const int code = (int)((4u - record_tag(make_uint2(lo, hi), bl)) & 3u);
                 if (code == 1) { --y; --x; }
                 else if (code == 2) { --y; }
                 else if (code == 3) { --x; }
@@ -964,8 +846,6 @@ constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uin
 // fewer walks per wavefront (more wavefronts per SIMD) made it SLOWER -- 3.79 / 4.16 / 5.76 ms with 64 / 32 / 16 walks per
 // wavefront -- and taking a fifth of the instructions out of the step did not show either: what is left is the latency of that
 // chain, ~555 cycles per step (profiles/r03_sg_traceback_experiments.txt).
-// PACKED = the records hold packed tags (split sweeps) rather than two ballot words per round (half-wavefront sweep).
-template <bool PACKED>
 __global__ void __launch_bounds__(64)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
@@ -983,7 +863,6 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
     unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
     int4 sum = summary[a];
-    sum.z &= 31;
     int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
     int x = sum.y - y;                                    // y + x = the round of the best cell
     // first window of the wavefront = the highest one any of its walks starts in
@@ -1056,9 +935,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
             const int top = (int)r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
             const int bl = 31 - (y - top);
             // tag of the cell's predecessor: 3 diagonal, 2 up, 1 left (never 0 on a live path)
-            unsigned tag;
-            if constexpr (PACKED) tag = (unsigned)((((unsigned long long)cw.y << 32) | cw.x) >> (2 * bl)) & 3u;
-            else tag = ((cw.x >> bl) & 1u) | (((cw.y >> bl) & 1u) << 1);
+            const unsigned tag = record_tag(cw, bl);
             y -= (int)(tag >> 1);                         // diagonal, up: one row back
             x -= (int)(tag & 1u);                         // diagonal, left: one column back
             r = (unsigned)(y + x);
@@ -1198,10 +1075,11 @@ size_t semiglobal_workspace_bytes(size_t n)
 }
 
 namespace {
-// Which sweep a batch of n alignments runs: 0 / 100 + W = band per half-wavefront (one cell per lane, sg_forward_kernel: kept
-// for comparison, no batch size picks it any more); 10 * G + W = band over G lanes (G = 4, 2: sg_forward_split_kernel, 8 / 16
-// cells per lane, 16 / 32 alignments per wavefront; G = 1: sg_forward_lane_kernel, 64 per wavefront), compiled for W
-// resident wavefronts per SIMD.  swmi_semiglobal_set_mapping / SWMI_SG_SWEEP force one: 0, G or 10 * G + W.  The kernels
+// Which sweep a batch of n alignments runs: 10 * G + W = band over G lanes (G = 4, 2: sg_forward_split_kernel, 8 / 16 cells per
+// lane, 16 / 32 alignments per wavefront; G = 1: sg_forward_lane_kernel, 64 per wavefront), compiled for W resident
+// wavefronts per SIMD.  swmi_semiglobal_set_mapping / SWMI_SG_SWEEP force one: G or 10 * G + W.  (Rounds 1-2 had a third
+// mapping, one band cell per lane: the packed split sweep beats it down to a batch of ONE alignment, 9.5 against 10.2 ms,
+// profiles/r03_sg_small_batches.txt, and it is gone -- with it the second record format.)  The kernels
 // are compiled once per scheduling target W (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per
 // SIMD, and the version whose W matches what the batch actually puts on a SIMD wins by 20-40 %.
 int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
@@ -1223,7 +1101,6 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
     if (t2 <= t1) return 20 + (w2 < 1 ? 1 : w2 > 4 ? 4 : w2);
     return 10 + (w1 < 1 ? 1 : w1 > 3 ? 3 : w1);
 }
-inline bool sweep_is_split(int sweep) { return sweep >= 11 && sweep <= 44; }            // packed tag records (every mapping but the half-wavefront one)
 inline int sweep_lanes(int sweep) { return sweep / 10; }
 bool choose_lane_traceback(size_t n, const SgTuning &tuning)
 {
@@ -1236,16 +1113,11 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
 {
     const int sweep = choose_sweep(n, compute_units, tuning);
     if (sweep_name && sweep_len) {
-        if (sweep_is_split(sweep) && sweep_lanes(sweep) == 1)
-            snprintf(sweep_name, sweep_len, "sg_forward_lane_kernel<%d>", sweep % 10);
-        else if (sweep_is_split(sweep))
-            snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep_lanes(sweep), sweep % 10);
-        else snprintf(sweep_name, sweep_len, "sg_forward_kernel<%d>", sweep > 100 && sweep <= 103 ? sweep - 100 : 8);
+        if (sweep_lanes(sweep) == 1) snprintf(sweep_name, sweep_len, "sg_forward_lane_kernel<%d>", sweep % 10);
+        else snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep_lanes(sweep), sweep % 10);
     }
     if (tb_name && tb_len)
-        snprintf(tb_name, tb_len, "%s", !choose_lane_traceback(n, tuning) ? "sg_traceback_kernel"
-                                        : sweep_is_split(sweep) ? "sg_walk_lane_kernel<1> + sg_expand_kernel"
-                                                                    : "sg_walk_lane_kernel<0> + sg_expand_kernel");
+        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n, tuning) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
@@ -1262,7 +1134,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     const int sweep = choose_sweep(n, compute_units, tuning);
-    if (sweep_is_split(sweep)) {
+    {
         const uint32_t per_block = 64 / sweep_lanes(sweep);                 // alignments per sweep wavefront: 64 / G
         const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
         hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
@@ -1289,27 +1161,14 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
         }
 #undef SWMI_SG_LAUNCH
 #undef SWMI_SG_LAUNCH1
-    } else {
-        const unsigned waves = (unsigned)((n + 1) / 2);
-        const dim3 grid((waves + 3) / 4);
-        const int w = sweep > 100 && sweep <= 103 ? sweep - 100 : 0;
-        if (w == 1) hipLaunchKernelGGL(sg_forward_kernel<1>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
-        else if (w == 2) hipLaunchKernelGGL(sg_forward_kernel<2>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
-        else if (w == 3) hipLaunchKernelGGL(sg_forward_kernel<3>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
-        else hipLaunchKernelGGL(sg_forward_kernel<8>, grid, dim3(256), 0, stream, d_seq1s, d_seq2s, (uint32_t)n, codes, top, summary);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
     const bool lane_tb = choose_lane_traceback(n, tuning);
     if (lane_tb) {
-        // the record format follows the sweep: packed tags from the split sweeps, two ballot words from the half-wavefront one
-        if (sweep_is_split(sweep))
-            hipLaunchKernelGGL(sg_walk_lane_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
-                               summary, moves, d_scores, d_lengths);
-        else
-            hipLaunchKernelGGL(sg_walk_lane_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
-                               summary, moves, d_scores, d_lengths);
+        hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
+                           summary, moves, d_scores, d_lengths);
         hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
                            d_tracebacks, (uint32_t)cap);
     }

@@ -72,7 +72,7 @@ void read_knobs()
     k.extra_lds = (unsigned)num("SWMI_EXTRA_LDS", 0, 160 * 1024, 0);
     k.lanes = (int)num("SWMI_LANES", 0, 64, 0);
     k.banded_no_i16 = getenv("SWMI_BANDED_NO_I16") != nullptr;
-    k.sg_sweep = (int)num("SWMI_SG_SWEEP", 0, 199, -1);
+    k.sg_sweep = (int)num("SWMI_SG_SWEEP", 1, 44, -1);
     k.sg_traceback = (int)num("SWMI_SG_TRACEBACK", 0, 1, -1);
     const char *gb = getenv("SWMI_GATHER_BACKEND");
     k.gather_p2p = gb && strcmp(gb, "p2p") == 0;
@@ -454,7 +454,8 @@ int init_list(const int *devices, int n)
     (void)hipSetDevice(devices[0]);
     g_ctxs = std::move(fresh);
     if (knobs().lanes && swmi::schedule_supported(knobs().lanes)) g_schedule.store(uint64_t(knobs().lanes));
-    sg_mapping_word().store(uint64_t(uint32_t(knobs().sg_sweep + 1)) | (uint64_t(uint32_t(knobs().sg_traceback + 1)) << 32));
+    if (swmi_semiglobal_set_mapping(knobs().sg_sweep, knobs().sg_traceback) != SWMI_OK)     // (a value it rejects: automatic)
+        (void)swmi_semiglobal_set_mapping(-1, knobs().sg_traceback);
     return SWMI_OK;
 }
 
@@ -847,10 +848,10 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
 
 int swmi_semiglobal_set_mapping(int sweep, int traceback)
 {
-    const bool sweep_ok = sweep == -1 || sweep == 0 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 14) ||
-                          (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44) || (sweep >= 101 && sweep <= 103);
+    const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 14) ||
+                          (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44);
     if (!sweep_ok || traceback < -1 || traceback > 1)
-        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 0, 1, 2, 4, 11..14, 21..24, 41..44 or 101..103, traceback -1, 0 or 1",
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 1, 2, 4, 11..14, 21..24 or 41..44, traceback -1, 0 or 1",
                     sweep, traceback);
     sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)) | (uint64_t(uint32_t(traceback + 1)) << 32));
     return SWMI_OK;

@@ -1,4 +1,6 @@
-"""Half-wavefront sweep (mapping 0) against the packed split sweep (41) for the smallest batches: ms per call, device inputs."""
+"""The split sweep (41, 21) and what the library picks for the smallest batches: ms per call, device inputs.
+(Run on commit 662c169.. with `for sweep in (0, 41, 21, -1)` it produced profiles/r03_sg_small_batches.txt: the half-wavefront
+sweep, mapping 0, lost at every size and was removed.)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "smith-waterman-simd_amd"))
@@ -15,7 +17,7 @@ for n in (1, 2, 16, 64, 256, 1024, 2048):
     tb = torch.empty((n, cap, 2), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     out = []
-    for sweep in (0, 41, 21, -1):
+    for sweep in (41, 21, -1):
         swmi.semiglobal_set_mapping(sweep, -1)
         swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         a, b = swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
