@@ -286,7 +286,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     }
     int pos_x = 31;
     int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
-    bool alive = true;
+    int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     if (is_first) stage_codes[al][0] = make_uint2(0, 0);
     // This lane's character stream: the first slice feeds on seq1 (consumed when the band steps down), the last slice on
@@ -336,12 +336,13 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
     auto one_round = [&](const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
         // source.cpp:1895: band cell 0 (first lane, register 0, low half) against band cell 31 (last lane, last register, high half)
-        const bool right = ((unsigned)group_first(cur[0]) & 0xFFFFu) < ((unsigned)group_last(cur[NV - 1]) >> 16);
-        const int rmask = keep_opaque(right ? -1 : 0);
+        // All of a round's decisions are arithmetic masks (sign of a difference, shifted down): a compare writes a scalar
+        // register pair and the select that reads it waits for it -- with one or two wavefronts on the SIMD nothing fills that wait
+        const int rmask = keep_opaque((int)((unsigned)group_first(cur[0]) & 0xFFFFu) - (int)((unsigned)group_last(cur[NV - 1]) >> 16)) >> 31;
         pos_x -= rmask;                                   // += 1 when the band steps right
         dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);   // (dir_word >> 1) | (right << 31)
         const int pos_y = round - (pos_x - 31);
-        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
+        alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;    // :1903, :1913: both still inside
         // neighbours of the slice in the previous round's band
         // register "-1" = cells (-1, NV - 1), register "NV" = cells (NV, C): the neighbour lane's end cell in one half, this
         // lane's own middle cell in the other (0 = dropped past the band's ends)
@@ -439,9 +440,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         // derived only from dropped cells (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
         --off;
         const int stored = kmax >> 7, band_best = stored + off;
-        const int round_best = stored > 3 && band_best > 0 ? band_best : 0;
-        const bool improved = alive && round_best > best; // :1933-1936
-        const int imask = keep_opaque(improved ? -1 : 0);
+        const int round_best = max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
+        const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = pick(imask, round_best, best);
         best_round = pick(imask, round, best_round);
         best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
@@ -474,7 +474,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
             off += delta;
         }
-        alive = alive && round_best != 0;                 // :1943-1946
+        alive_m &= keep_opaque(-round_best) >> 31;        // alive && round_best != 0 (:1943-1946)
         last_round = round;
     };
 
@@ -483,7 +483,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // the up to 15 rounds a finished wavefront runs on change nothing (no alignment is alive to improve, and the records of
     // rounds after an alignment's best round are never read).
     for (int round = 1; round < kMaxRound; round += 2) {
-        if ((round & 15) == 1 && !__any(alive)) break;
+        if ((round & 15) == 1 && !__any(alive_m != 0)) break;
         one_round(round, sp_a, sp_b);
         one_round(round + 1, sp_b, sp_a);
     }
@@ -600,18 +600,20 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     sb.start(stream_a + 1, kStreamStride, 0);
     int pos_x = 31;
     int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
-    bool alive = true;
+    int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     stage_codes[lane][0] = make_uint2(0, 0);
 
     auto one_round = [&](const int round, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
-        const bool right = (cur[0] & 0xFFFFu) < (cur[NV - 1] >> 16);          // source.cpp:1895: band cell 0 against band cell 31
-        const int rmask = keep_opaque(right ? -1 : 0);
+        // source.cpp:1895: band cell 0 against band cell 31.  All of a round's decisions are arithmetic masks (sign of a
+        // difference, shifted down): a compare writes a scalar register pair and the select that reads it waits for it, and
+        // with one wavefront on the SIMD nothing fills that wait
+        const int rmask = keep_opaque((int)(cur[0] & 0xFFFFu) - (int)(cur[NV - 1] >> 16)) >> 31;
         const unsigned rm = (unsigned)rmask, dm = ~rm;
         pos_x -= rmask;
         dir_word = __builtin_amdgcn_alignbit(rm, dir_word, 1);
         const int pos_y = round - (pos_x - 31);
-        alive = alive && pos_x <= 32 + kLen + 31 && pos_y <= 1 + kLen;        // :1903, :1913
+        alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;    // :1903, :1913: both still inside
         // the windows follow the band: seq1's moves up one field on a step down, seq2's down one field on a step right
         {
             const unsigned a_in = sa.next(), b_in = sb.next();
@@ -685,9 +687,8 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         // (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
         --off;
         const int stored = kmax >> 7, band_best = stored + off;
-        const int round_best = stored > 3 && band_best > 0 ? band_best : 0;
-        const bool improved = alive && round_best > best;                     // :1933-1936
-        const int imask = keep_opaque(improved ? -1 : 0);
+        const int round_best = max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
+        const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = (int)pick(imask, (unsigned)round_best, (unsigned)best);
         best_round = (int)pick(imask, (unsigned)round, (unsigned)best_round);
         best_lane = (int)pick(imask, (unsigned)(kmax >> 2) & 31u, (unsigned)best_lane);  // highest cell among equals (:1957)
@@ -715,12 +716,12 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
             for (int k = 0; k <= NV; ++k) sp_next[k] = sg_pk_sub_sat(sp_next[k], d2);
             off += delta;
         }
-        alive = alive && round_best != 0;                 // :1943-1946
+        alive_m &= keep_opaque(-round_best) >> 31;        // alive && round_best != 0 (:1943-1946)
         last_round = round;
     };
 
     for (int round = 1; round < kMaxRound; round += 2) {  // (the exit test once per 16 rounds: see the split sweep)
-        if ((round & 15) == 1 && !__any(alive)) break;
+        if ((round & 15) == 1 && !__any(alive_m != 0)) break;
         one_round(round, sp_a, sp_b);
         one_round(round + 1, sp_b, sp_a);
     }
@@ -1094,7 +1095,7 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
     // with a single wavefront issues an instruction every ~6 cycles instead of every ~4.3.
     const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
     const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds), w1 = (int)((n / 64 + simds - 1) / simds);
-    const double t4 = 3.6 + 6.2 * (w4 < 1 ? 1 : w4), t2 = 3.6 + 9.0 * (w2 < 1 ? 1 : w2), t1 = w1 <= 1 ? 21.0 : 3.7 + 16.05 * w1;
+    const double t4 = 3.6 + 6.2 * (w4 < 1 ? 1 : w4), t2 = 3.6 + 9.0 * (w2 < 1 ? 1 : w2), t1 = w1 <= 1 ? 20.4 : 3.7 + 16.05 * w1;
     // the build whose scheduling target equals the wavefronts a SIMD actually gets (at most 4; the lane kernel's 145 registers
     // fit three per SIMD)
     if (t4 <= t2 && t4 <= t1) return 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4);
