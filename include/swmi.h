@@ -235,14 +235,13 @@ SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, s
  * different streams use different workspaces and may be in flight together, from any threads. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
-/* Which kernels the aligner runs is chosen from the batch size; this overrides the choice, the way
- * swmi_set_schedule does for the scorer -- every mapping returns the same (score, traceback), tests/test_semiglobal.py runs
- * them all.  sweep: -1 = automatic, 4 / 2 / 1 = the band over 4 / 2 lanes or in one lane (16 / 32 / 64 alignments per
- * wavefront), 10 * lanes + W = that mapping compiled for W wavefronts per SIMD (41..44, 21..24, 11..14); traceback: -1 =
- * automatic, 1 = one lane per walk + expand kernel, 0 = one wavefront per walk.  Anything else: SWMI_ERR_INVALID_ARGUMENT.
- * Process-wide, one atomic word.  SWMI_SG_SWEEP / SWMI_SG_TRACEBACK in the environment set the initial value at swmi_init*
- * (a value this call would reject is ignored). */
-SWMI_API int swmi_semiglobal_set_mapping(int sweep, int traceback);
+/* Which sweep kernel the aligner runs is chosen from the batch size; this overrides the choice, the
+ * way swmi_set_schedule does for the scorer -- every mapping returns the same (score, traceback), tests/test_semiglobal.py
+ * runs them all.  sweep: -1 = automatic, 4 / 2 / 1 = the band over 4 / 2 lanes or in one lane (16 / 32 / 64 alignments per
+ * wavefront), 10 * lanes + W = that mapping compiled for W wavefronts per SIMD (41..44, 21..24, 11..14).  Anything else:
+ * SWMI_ERR_INVALID_ARGUMENT.  Process-wide, one atomic word.  SWMI_SG_SWEEP in the environment sets the initial value at
+ * swmi_init* (a value this call would reject is ignored).  (The traceback has one mapping: a lane per walk + expand kernel.) */
+SWMI_API int swmi_semiglobal_set_mapping(int sweep);
 /* Free the per-stream workspaces of the current GPU (synchronises the device first). */
 SWMI_API int swmi_semiglobal_release_workspaces(void);
 /* Names of the sweep and traceback kernels a call with n alignments runs on the current GPU (the mapping depends on the

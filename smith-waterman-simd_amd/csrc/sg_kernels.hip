@@ -12,8 +12,8 @@
 //     max, in the reference's own tie-break order :1962-1971) = 8 bytes, and ONE bit for the band's move (right / down);
 //     the row of the band's top cell is rebuilt from the move bits (round - right moves so far = a popcount).
 //   * traceback: follows the codes from the best cell back to (0,0) and returns the positions in ascending order, as the
-//     reference does (:1951-1975): one wavefront per walk (sg_traceback_kernel, small batches) or one lane per walk that
-//     records its moves + a prefix-sum kernel that expands them (sg_walk_lane_kernel, sg_expand_kernel, large batches).
+//     reference does (:1951-1975): one lane per walk that records its moves (sg_walk_lane_kernel) + a prefix-sum kernel
+//     that expands them into positions (sg_expand_kernel).
 #include "swmi_internal.h"
 
 #include <cstdio>
@@ -42,9 +42,6 @@ __device__ __forceinline__ size_t code_index(uint32_t n, uint32_t a, int round) 
 // move bits: bit (r & 31) of word r >> 5 = 1 when the band stepped right in round r (source.cpp:1895); stored
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
 constexpr int kDirWords = kMaxRound / 32 + 1;
-// which mapping for which batch (tools/sg_sweep_matrix.py, profiles/r01_sg_kernel_matrix.txt)
-constexpr size_t kLaneTracebackMinBatch = 2048;  // one lane per walk (+ expand kernel) from here on
-
 // Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
 // three-way max: 3 diagonal, 2 up, 1 left (0: round 0 / nothing) -- the reference's tie-break order (source.cpp:1962-1971)
 // falls out of comparing equal values by tag -- band cell k at bits 2k..2k+1 of the round's 64 bits.
@@ -732,101 +729,11 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     }
 }
 
-// Traceback: one wavefront per alignment.  The walk itself is scalar (y, x and the round live in SGPRs); the lanes hold
-// 64 consecutive rounds of (code words, band row) each, fetched with coalesced loads one block ahead of the walker, and
-// the walker picks its round with v_readlane.  The band row of a round is rebuilt from the move bits: row of the top cell
-// = round - (right moves up to and including the round) -- a popcount over the block's 64 bits below the lane.  Two walks: the first counts the steps, the second writes the positions
-// at their final (ascending) index, 64 at a time.
-__global__ void __launch_bounds__(64)
-sg_traceback_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
-                    const int4 *__restrict__ summary, int32_t *__restrict__ scores, int32_t *__restrict__ tracebacks,
-                    uint32_t cap, uint32_t *__restrict__ lengths)
-{
-    const uint32_t a = blockIdx.x;
-    const int lane = threadIdx.x;
-    const uint2 *all_codes = reinterpret_cast<const uint2 *>(codes);
-    const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]
-    int4 sum = summary[a];
-    const int y0 = sum.w + 31 - sum.z;                    // .w = row of the band's top cell in the best round
-    const int x0 = sum.y - y0;
-    int2 *out = reinterpret_cast<int2 *>(tracebacks) + (size_t)a * cap;
-
-    // With room for the longest possible path the positions are written once, in walking (descending) order, and the
-    // wavefront reverses them in place afterwards; a smaller `cap` needs the count first (two walks).
-    const bool one_walk = cap >= (uint32_t)kMaxRound;
-    uint32_t total = 0;
-    for (int pass = one_walk ? 1 : 0; pass < 2; ++pass) {
-        int y = y0, x = x0;
-        int base = ((y + x) >> 6) << 6;                   // lanes hold rounds base .. base+63 (cur) and base-64 .. base-1 (nxt)
-        const unsigned long long below_me = (2ull << lane) - 1;               // the block's rounds up to and including this lane's
-        auto fetch = [&](int b, uint2 &cw, unsigned long long &bits) {       // codes of round b + lane; move bits of rounds b .. b + 63
-            const int r = b + lane;
-            const bool ok = b >= 0 && r < kMaxRound;
-            cw = ok ? all_codes[code_index(n, a, r)] : make_uint2(0, 0);
-            const int w = b >> 5;                          // b is a multiple of 64
-            const unsigned lo = b >= 0 ? my_dirs[(size_t)w * n] : 0u, hi = (b >= 0 && w + 1 < kDirWords) ? my_dirs[(size_t)(w + 1) * n] : 0u;
-            bits = ((unsigned long long)hi << 32) | lo;
-        };
-        uint2 cw, nw;
-        unsigned long long cbits, nbits;
-        fetch(base, cw, cbits);
-        fetch(base - 64, nw, nbits);
-        // right moves in the rounds before `base`: from the best round's band row, (best round - its right moves)
-        int rights_before = (sum.y - sum.w) - __popcll(cbits & ((2ull << (sum.y - base)) - 1));
-        int tw = (base + lane) - (rights_before + __popcll(cbits & below_me));
-        uint32_t count = 0;                               // positions emitted so far (descending order)
-        int by = 0, bx = 0;                               // this lane's slot of the 64-position output buffer
-        bool more = true;
-        while (more) {
-            // record the current position in slot count % 64
-            const int slot = (int)(count & 63u);
-            if (lane == slot) { by = y; bx = x; }
-            ++count;
-            more = (y | x) != 0;
-            if (more) {
-                const int r = y + x;
-                if (r < base) {                           // walked off the block: take the prefetched one, prefetch the next
-                    base -= 64;
-                    cw = nw; cbits = nbits;
-                    rights_before -= __popcll(cbits);
-                    tw = (base + lane) - (rights_before + __popcll(cbits & below_me));
-                    fetch(base - 64, nw, nbits);
-                }
-                const int idx = __builtin_amdgcn_readfirstlane(r - base);
-                const unsigned lo = __builtin_amdgcn_readlane(cw.x, idx), hi = __builtin_amdgcn_readlane(cw.y, idx);
-                const int top = __builtin_amdgcn_readlane(tw, idx);
-                const int bl = 31 - (y - top);
-                const int code = (int)((4u - record_tag(make_uint2(lo, hi), bl)) & 3u);
-                if (code == 1) { --y; --x; }
-                else if (code == 2) { --y; }
-                else if (code == 3) { --x; }
-                else more = false;                        // cannot happen for a cell on a live path
-            }
-            if (pass == 1 && (slot == 63 || !more)) {     // flush 64 buffered positions with one coalesced store
-                const uint32_t c = count - 1 - (uint32_t)slot + (uint32_t)lane;   // element number of this lane's slot
-                if (lane <= slot) {
-                    const uint32_t idx_out = one_walk ? c : total - 1 - c;
-                    if (idx_out < cap) out[idx_out] = make_int2(by, bx);
-                }
-            }
-        }
-        total = count;
-    }
-    if (one_walk) {                                       // reverse out[0 .. total) in place
-        __syncthreads();                                  // one wavefront per block: orders the stores above before the loads below
-        for (uint32_t i = (uint32_t)lane; i < total / 2; i += 64) {
-            const int2 lo_v = out[i], hi_v = out[total - 1 - i];
-            out[i] = hi_v;
-            out[total - 1 - i] = lo_v;
-        }
-    }
-    if (lane == 0) { scores[a] = sum.x; lengths[a] = total; }
-}
-
-// Traceback for large batches, two kernels.
+// Traceback, two kernels.
 //
-// sg_walk_lane_kernel: one LANE per walk (the wave-per-alignment walker above is bound by the scalar unit: one walk per
-// wavefront, ~40 scalar instructions per step; here 64 walks advance per vector instruction).  The 64 walks of a wavefront
+// sg_walk_lane_kernel: one LANE per walk (rounds 1-2 also had a walker with one wavefront per alignment, y and x in scalar
+// registers, for small batches: ~40 scalar instructions per step -- this pair beats it down to a batch of one alignment,
+// profiles/r03_sg_traceback_small.txt, and it is gone).  The 64 walks of a wavefront
 // move in LOCKSTEP BY WINDOW of 16 rounds = one 128-byte line of code records per walk: all lanes consume window w (each at
 // its own pace, 8..16 steps) out of LDS, then the whole wavefront swaps in the line of window w-1.  (Refilling per lane,
 // whenever a walk left its line, made almost every step wait for some lane's load: 64 walks at random phases.)
@@ -1103,10 +1010,6 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
     return 10 + (w1 < 1 ? 1 : w1 > 3 ? 3 : w1);
 }
 inline int sweep_lanes(int sweep) { return sweep / 10; }
-bool choose_lane_traceback(size_t n, const SgTuning &tuning)
-{
-    return tuning.force_traceback >= 0 ? tuning.force_traceback == 1 : n >= kLaneTracebackMinBatch;
-}
 }  // namespace
 
 void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len,
@@ -1118,7 +1021,7 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
         else snprintf(sweep_name, sweep_len, "sg_forward_split_kernel<%d, %d>", sweep_lanes(sweep), sweep % 10);
     }
     if (tb_name && tb_len)
-        snprintf(tb_name, tb_len, "%s", choose_lane_traceback(n, tuning) ? "sg_walk_lane_kernel + sg_expand_kernel" : "sg_traceback_kernel");
+        snprintf(tb_name, tb_len, "sg_walk_lane_kernel + sg_expand_kernel");
 }
 
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
@@ -1166,16 +1069,10 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
-    const bool lane_tb = choose_lane_traceback(n, tuning);
-    if (lane_tb) {
-        hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top,
-                           summary, moves, d_scores, d_lengths);
-        hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
-                           d_tracebacks, (uint32_t)cap);
-    }
-    else
-        hipLaunchKernelGGL(sg_traceback_kernel, dim3((unsigned)n), dim3(64), 0, stream, (uint32_t)n, codes, top, summary, d_scores,
-                           d_tracebacks, (uint32_t)cap, d_lengths);
+    hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top, summary,
+                       moves, d_scores, d_lengths);
+    hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
+                       d_tracebacks, (uint32_t)cap);
     return hipGetLastError();
 }
 

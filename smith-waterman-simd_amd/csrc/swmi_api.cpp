@@ -26,8 +26,8 @@ bool g_knobs_read = false;
 // Schedule setting, process-wide: lanes in the low half, flags in the high half, ONE atomic so that a launch that races
 // with swmi_set_schedule sees either the old pair or the new one, never a mix.
 std::atomic<uint64_t> g_schedule{0};
-// Mapping override of the semi-global kernels (swmi_semiglobal_set_mapping; SWMI_SG_SWEEP / SWMI_SG_TRACEBACK give the initial
-// value at swmi_init): ONE atomic word, sweep in the low half, traceback in the high half, each + 1 so that 0 = automatic.
+// Mapping override of the semi-global sweep (swmi_semiglobal_set_mapping; SWMI_SG_SWEEP gives the initial
+// value at swmi_init): one atomic word, the mapping + 1 so that 0 = automatic.
 std::atomic<uint64_t> g_sg_mapping{0};
 }  // namespace
 
@@ -73,7 +73,6 @@ void read_knobs()
     k.lanes = (int)num("SWMI_LANES", 0, 64, 0);
     k.banded_no_i16 = getenv("SWMI_BANDED_NO_I16") != nullptr;
     k.sg_sweep = (int)num("SWMI_SG_SWEEP", 1, 44, -1);
-    k.sg_traceback = (int)num("SWMI_SG_TRACEBACK", 0, 1, -1);
     const char *gb = getenv("SWMI_GATHER_BACKEND");
     k.gather_p2p = gb && strcmp(gb, "p2p") == 0;
     k.gather_piece = (size_t)num("SWMI_TEST_GATHER_PIECE", 1, 1ll << 40, 0);
@@ -454,8 +453,7 @@ int init_list(const int *devices, int n)
     (void)hipSetDevice(devices[0]);
     g_ctxs = std::move(fresh);
     if (knobs().lanes && swmi::schedule_supported(knobs().lanes)) g_schedule.store(uint64_t(knobs().lanes));
-    if (swmi_semiglobal_set_mapping(knobs().sg_sweep, knobs().sg_traceback) != SWMI_OK)     // (a value it rejects: automatic)
-        (void)swmi_semiglobal_set_mapping(-1, knobs().sg_traceback);
+    if (swmi_semiglobal_set_mapping(knobs().sg_sweep) != SWMI_OK) (void)swmi_semiglobal_set_mapping(-1);   // (a value it rejects: automatic)
     return SWMI_OK;
 }
 
@@ -727,7 +725,6 @@ static swmi::SgTuning sg_tuning()
     const uint64_t m = sg_mapping_word().load(std::memory_order_relaxed);
     swmi::SgTuning t;
     t.force_sweep = int(m & 0xffffffffu) - 1;
-    t.force_traceback = int(m >> 32) - 1;
     return t;
 }
 
@@ -846,14 +843,12 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
     return semiglobal_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream, nullptr);
 }
 
-int swmi_semiglobal_set_mapping(int sweep, int traceback)
+int swmi_semiglobal_set_mapping(int sweep)
 {
     const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 14) ||
                           (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44);
-    if (!sweep_ok || traceback < -1 || traceback > 1)
-        return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d / traceback %d: sweep is -1, 1, 2, 4, 11..14, 21..24 or 41..44, traceback -1, 0 or 1",
-                    sweep, traceback);
-    sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)) | (uint64_t(uint32_t(traceback + 1)) << 32));
+    if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..14, 21..24 or 41..44", sweep);
+    sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)));
     return SWMI_OK;
 }
 

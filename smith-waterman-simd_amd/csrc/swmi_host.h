@@ -31,7 +31,6 @@ struct Knobs {
     int lanes = 0;                  // SWMI_LANES: initial schedule
     bool banded_no_i16 = false;     // SWMI_BANDED_NO_I16
     int sg_sweep = -1;              // SWMI_SG_SWEEP: force a semi-global sweep mapping (sg_kernels.hip choose_sweep)
-    int sg_traceback = -1;          // SWMI_SG_TRACEBACK: 1 = lane-per-walk traceback, 0 = wavefront-per-walk
     bool gather_p2p = false;        // SWMI_GATHER_BACKEND=p2p: never RCCL
     size_t gather_piece = 0;        // SWMI_TEST_GATHER_PIECE: ragged RCCL gather even for equal shards, shards broadcast in
                                     //   pieces of this many scores (rehearses the ragged path with one rank)

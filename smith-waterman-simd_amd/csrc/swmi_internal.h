@@ -52,10 +52,9 @@ bool schedule_supported(int lanes_per_alignment);
 
 // Semi-global adaptive-band X-drop aligner (sg_kernels.hip). Workspace: codes + band rows + summaries for n alignments.
 size_t semiglobal_workspace_bytes(size_t n);
-// Experiment switches of the mapping choice (read from SWMI_SG_SWEEP / SWMI_SG_TRACEBACK once, at swmi_init): -1 = automatic
+// Override of the sweep mapping (swmi_semiglobal_set_mapping; SWMI_SG_SWEEP gives the initial value at swmi_init): -1 = automatic
 struct SgTuning {
-    int force_sweep = -1;        // 0, G or 10 * G + W (sg_kernels.hip choose_sweep)
-    int force_traceback = -1;    // 1 = one lane per walk (+ expand), 0 = one wavefront per walk
+    int force_sweep = -1;        // G or 10 * G + W (sg_kernels.hip choose_sweep)
 };
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,

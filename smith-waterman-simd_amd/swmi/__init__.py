@@ -411,9 +411,9 @@ def semiglobal_time_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_l
     return float(ms[0]), float(ms[1])
 
 
-def semiglobal_set_mapping(sweep=-1, traceback=-1):
-    """Override which semi-global kernels run (-1 = automatic); see swmi_semiglobal_set_mapping in include/swmi.h."""
-    _check(load().swmi_semiglobal_set_mapping(int(sweep), int(traceback)))
+def semiglobal_set_mapping(sweep=-1):
+    """Override which semi-global sweep runs (-1 = automatic); see swmi_semiglobal_set_mapping in include/swmi.h."""
+    _check(load().swmi_semiglobal_set_mapping(int(sweep)))
 
 
 def semiglobal_kernels_for_batch(n):

@@ -30,17 +30,16 @@ def test_oracle_reproduces_the_reference_results(oracle, golden):
 
 @pytest.fixture
 def sg_kernels(swmi_mod):
-    """Select the sweep mapping (0 = band per half-wavefront, 4 / 2 = band split over 4 / 2 lanes) and the traceback
-    mapping (0 = wavefront per walk, 1 = lane per walk) through swmi_semiglobal_set_mapping; by default the batch size decides."""
+    """Select the sweep mapping (4 / 2 / 1 = band over 4 / 2 lanes / in one lane, 10 * lanes + W = a scheduling target)
+    through swmi_semiglobal_set_mapping; by default the batch size decides."""
     yield swmi_mod.semiglobal_set_mapping
-    swmi_mod.semiglobal_set_mapping(-1, -1)
+    swmi_mod.semiglobal_set_mapping(-1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(4, 0), (4, 1), (2, 1), (1, 1), (2, 0), (1, 0), (41, 1), (42, 0), (43, 1),
-                                             (21, 1), (22, 1), (23, 0), (11, 1), (12, 0), (14, 1)])
-def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep, traceback):
-    sg_kernels(sweep, traceback)
+@pytest.mark.parametrize("sweep", [4, 2, 1, 41, 42, 43, 21, 22, 23, 11, 12, 14])
+def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep):
+    sg_kernels(sweep)
     f = golden("f6_semiglobal")
     paths = _paths_from_fixture(f)
     scores, tbs, lengths = gpu.semiglobal_xdrop(f["seq1"], f["seq2"])
@@ -51,11 +50,11 @@ def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, swee
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(4, 0), (4, 1), (2, 1), (1, 1), (22, 1), (41, 0), (12, 1)])
-def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, sweep, traceback):
-    sg_kernels(sweep, traceback)
+@pytest.mark.parametrize("sweep", [4, 2, 1, 22, 41, 12])
+def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, sweep):
+    sg_kernels(sweep)
     rng = np.random.default_rng(77)
-    n = 21 if traceback == 0 else 70             # odd / not a multiple of 64: ragged last wavefront
+    n = 21 if sweep == 4 else 70                 # odd / not a multiple of 64: ragged last wavefront
     a = rng.integers(0, 4, (n, 16384), dtype=np.uint8)
     b = np.zeros_like(a)
     for k in range(n):                           # indel-rich relatives at different divergence (TestSemiGlobal's recipe)
@@ -82,9 +81,9 @@ def test_gpu_semiglobal_matches_oracle_on_fresh_inputs(gpu, oracle, sg_kernels, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(4, 0), (4, 1), (2, 1), (1, 1)])
-def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep, traceback):
-    sg_kernels(sweep, traceback)
+@pytest.mark.parametrize("sweep", [4, 2, 1])
+def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep):
+    sg_kernels(sweep)
     rng = np.random.default_rng(4)
     a = rng.integers(0, 4, (2, 16384), dtype=np.uint8)
     b = a.copy()
@@ -141,12 +140,12 @@ def test_gpu_semiglobal_host_entry_pipelines_chunks(gpu, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(4, 0), (4, 1), (2, 1), (1, 1)])
-def test_gpu_semiglobal_bytes_that_are_no_base(gpu, oracle, sg_kernels, sweep, traceback):
+@pytest.mark.parametrize("sweep", [4, 2, 1])
+def test_gpu_semiglobal_bytes_that_are_no_base(gpu, oracle, sg_kernels, sweep):
     """Outside the reference's domain (its traceback indexes the 4x4 matrix with the raw byte, source.cpp:1961), but defined
     here: a byte >= 4 scores as a mismatch against everything, also against itself -- the meaning the reference's sweep
     gives it (:1918-1920).  Oracle and every GPU mapping agree."""
-    sg_kernels(sweep, traceback)
+    sg_kernels(sweep)
     rng = np.random.default_rng(8)
     a = rng.integers(0, 4, (3, 16384), dtype=np.uint8)
     b = a.copy()
@@ -163,10 +162,10 @@ def test_gpu_semiglobal_bytes_that_are_no_base(gpu, oracle, sg_kernels, sweep, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,traceback", [(4, 0), (2, 1), (1, 1)])
-def test_gpu_semiglobal_scores_only(gpu, oracle, sg_kernels, sweep, traceback):
+@pytest.mark.parametrize("sweep", [4, 2, 1])
+def test_gpu_semiglobal_scores_only(gpu, oracle, sg_kernels, sweep):
     """cap = 0: scores and path lengths without any positions (the traceback buffer may be absent)."""
-    sg_kernels(sweep, traceback)
+    sg_kernels(sweep)
     rng = np.random.default_rng(12)
     a = rng.integers(0, 4, (5, 16384), dtype=np.uint8)
     b = a.copy()

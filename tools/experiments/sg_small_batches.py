@@ -18,7 +18,7 @@ for n in (1, 2, 16, 64, 256, 1024, 2048):
     st = torch.cuda.current_stream().cuda_stream
     out = []
     for sweep in (41, 21, -1):
-        swmi.semiglobal_set_mapping(sweep, -1)
+        swmi.semiglobal_set_mapping(sweep)
         swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         a, b = swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         out.append("%s %.2f + %.2f ms (checksum %d)" % (sweep, a, b, int(scores.sum().item()) + int(lengths.sum().item())))

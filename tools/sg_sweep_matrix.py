@@ -24,18 +24,16 @@ for n in sizes:
     tb = torch.empty((n, cap, 2), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     ref = None
-    variants = ((-1, -1), (4, 0), (4, 1), (2, 1), (1, 1))              # -1 = what the library picks for this batch size
-    if os.environ.get("SG_MATRIX_SWEEPS"):               # e.g. "41,42,44,22,24": 10 * lanes + scheduling target, lane traceback
-        variants = tuple((int(v), 1) for v in os.environ["SG_MATRIX_SWEEPS"].split(","))
-    for sweep, trace in variants:
-        if trace == 0 and n > 65536:
-            continue
-        swmi.semiglobal_set_mapping(sweep if sweep >= 0 else -1, trace if sweep >= 0 else -1)
+    variants = (-1, 4, 2, 1)                              # -1 = what the library picks for this batch size
+    if os.environ.get("SG_MATRIX_SWEEPS"):               # e.g. "41,42,44,22,24,11": 10 * lanes + scheduling target
+        variants = tuple(int(v) for v in os.environ["SG_MATRIX_SWEEPS"].split(","))
+    for sweep in variants:
+        swmi.semiglobal_set_mapping(sweep)
         swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         a, b = swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         chk = (int(scores.sum().item()), int(lengths.sum().item()), int(tb[:: max(1, n // 64), :4096].sum().item()))
         ref = ref or chk
-        print("n %7d sweep %2d traceback %d: sweep %8.2f ms traceback %8.2f ms  -> %8.1f k alignments/s %s" % (
-            n, sweep, trace, a, b, n / (a + b), "" if chk == ref else "MISMATCH"), flush=True)
+        print("n %7d sweep %2d: sweep %8.2f ms traceback %8.2f ms  -> %8.1f k alignments/s %s" % (
+            n, sweep, a, b, n / (a + b), "" if chk == ref else "MISMATCH"), flush=True)
     del d1, d2, tb
     torch.cuda.empty_cache()
