@@ -741,19 +741,22 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
 // gives -- so what counts is bytes in flight: THREE windows per walk are requested ahead (three register buffers that
 // rotate through the roles, the loop is unrolled by three; 384 bytes per walk in flight; round 2: 64-byte half lines, one
 // ahead, 3.5 TB/s).  The walk does not write positions -- their index in the ascending list is unknown until (0,0) is
-// reached -- but its moves, 2 bits per step (1 diag, 2 up, 3 left), 8 KB per alignment at most.
+// reached -- but its moves, 2 bits per step (the tags: 3 diag, 2 up, 1 left), 8 KB per alignment at most.
 //
-// sg_expand_kernel: one wavefront per alignment turns the moves into the (i, j) list of source.cpp:1951-1975, in
+// sg_expand_kernel: one wavefront per alignment turns the moves (the tags) into the (i, j) list of source.cpp:1951-1975, in
 // ascending order from (0,0) (see the kernel).
 constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
 constexpr int kWinQuads = kCodeWindow / 2;               // uint4 = two rounds; 8 per line
 constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uint4 (padded)
 
-// A step of a walk is one dependency chain (LDS read, decode, update of (y, x), next address) and the 65536 walks of the
-// bench batch are 1024 wavefronts, one per SIMD, so the kernel is bound by the instructions of that chain, not by memory:
-// fewer walks per wavefront (more wavefronts per SIMD) made it SLOWER -- 3.79 / 4.16 / 5.76 ms with 64 / 32 / 16 walks per
-// wavefront -- and taking a fifth of the instructions out of the step did not show either: what is left is the latency of that
-// chain, ~555 cycles per step (profiles/r03_sg_traceback_experiments.txt).
+// Inside a window the walks do not loop over their own steps (8 .. 16 of them, a different count per lane, each step one
+// chain LDS read -> decode -> (y, x) -> next address: ~400 cycles per step with one wavefront on the SIMD, 3.78 ms for 65536
+// walks).  Every lane takes its line into 32 registers and the wavefront goes through the window's SIXTEEN ROUNDS in
+// lockstep, round by round downwards: a lane whose walk stands in that round takes its step, the others (a diagonal step
+// skips a round) do nothing.  The record of a round is then a compile-time register, the band row of the round does not
+// depend on the walk (it is computed off the chain), and what is carried from round to round is -2 y and -round:
+//     active = (rho - r - 1) >> 31;  tag = (record >> (2 (31 + rho - rights) - 2 y)) & 3 & active;  -2y += tag & 2;  -r += popcount(tag)
+// 15 instructions per round, no branch, no memory access.  The moves leave as the raw tags (3 diag, 2 up, 1 left).
 __global__ void __launch_bounds__(64)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
@@ -779,8 +782,8 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
                max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
 
-    bool walking = (y | x) != 0;
-    uint32_t steps = 0;
+    int nr = -(y + x), ny2 = -2 * y;                      // minus the round of the walk's cell, minus twice its row
+    uint32_t steps = 0;                                   // moves made
     unsigned long long acc = 0;                           // the last (steps & 31) moves, 2 bits each
     // The WALKS lines of a window (one per walk of this wavefront) lie side by side in memory: the wavefront fetches them
     // COOPERATIVELY, 1 KB per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 8, quarter p % 8 -- and
@@ -835,26 +838,42 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     };
     enter_block();
     SG_TO_LDS(wa);
-    const uint2 *my_line = reinterpret_cast<const uint2 *>(&line_codes[lane * kLinePitch]);
+    const uint4 *my_line = &line_codes[lane * kLinePitch];
     auto walk_window = [&](int w) {
-        unsigned r = (unsigned)(y + x);                   // the round of the walk's cell (never negative)
-        while (walking && (r / kCodeWindow) == (unsigned)w) {
-            const uint2 cw = my_line[r & (kCodeWindow - 1)];
-            const int top = (int)r - (rights_before + (int)__popc(d_blk & ((2u << (r & 31)) - 1u)));
-            const int bl = 31 - (y - top);
-            // tag of the cell's predecessor: 3 diagonal, 2 up, 1 left (never 0 on a live path)
-            const unsigned tag = record_tag(cw, bl);
-            y -= (int)(tag >> 1);                         // diagonal, up: one row back
-            x -= (int)(tag & 1u);                         // diagonal, left: one column back
-            r = (unsigned)(y + x);
-            acc |= (unsigned long long)((4u - tag) & 3u) << (2 * (steps & 31u));     // the move: 1 diag, 2 up, 3 left
-            ++steps;
-            if ((steps & 31u) == 0) {
-                if (real) my_moves[(steps >> 5) - 1] = acc;
-                acc = 0;
+        uint4 rec[kWinQuads];                             // rounds 16 w + 2 j (.x, .y) and 16 w + 2 j + 1 (.z, .w)
+#pragma unroll
+        for (int j = 0; j < kWinQuads; ++j) rec[j] = my_line[j];
+        // the window's 16 move bits and the right moves before it
+        const bool upper = (w & 1) != 0;                  // (wave-uniform)
+        const unsigned d_win = upper ? d_blk >> 16 : d_blk & 0xFFFFu;
+        const int rb_win = rights_before + (upper ? (int)__popc(d_blk & 0xFFFFu) : 0);
+        unsigned wm = 0;                                  // this window's moves, cnt2 / 2 of them
+        int cnt2 = 0;
+#pragma unroll
+        for (int i = kCodeWindow - 1; i >= 0; --i) {
+            if (i > 0 || w > 0) {                         // (round 0 is the cell (0, 0): nothing to decode)
+                const int rho = kCodeWindow * w + i;
+                const unsigned long long cw = i & 1 ? ((unsigned long long)rec[i / 2].w << 32) | rec[i / 2].z
+                                                    : ((unsigned long long)rec[i / 2].y << 32) | rec[i / 2].x;
+                // band row of round rho = rho - (right moves up to and including rho); 2 * band cell of the walk = 2 (31 + top) - 2 y
+                const int rights = rb_win + (int)__popc(d_win & ((2u << i) - 1u));
+                const int shift = 2 * (31 + rho - rights) + ny2;
+                const int active = keep_opaque(nr + (rho - 1)) >> 31;         // r == rho (r <= rho always): all ones
+                const unsigned tag = (unsigned)(cw >> (shift & 63)) & 3u & (unsigned)active;    // 3 diagonal, 2 up, 1 left (never 0 on a live path)
+                ny2 += (int)(tag & 2u);                   // diagonal, up: one row back
+                nr += (int)__popc(tag);                   // diagonal: two rounds back, up / left: one
+                wm |= tag << cnt2;
+                cnt2 -= 2 * active;
             }
-            walking = tag != 0 && r != 0;
         }
+        // the window's moves behind the ones collected so far; a full word of 32 leaves
+        const int fill2 = 2 * (int)(steps & 31u);
+        acc |= (unsigned long long)wm << fill2;
+        if (fill2 + cnt2 >= 64) {                         // (then fill2 >= 32: the shift below is 2 .. 32)
+            if (real) my_moves[steps >> 5] = acc;
+            acc = (unsigned long long)wm >> (64 - fill2);
+        }
+        steps += (uint32_t)(cnt2 >> 1);
     };
     auto next_block = [&](int w) {                        // leaving window w > 0: window w - 1 comes next
         if ((w & 1) == 0) {                               // ... and lies in the 32-round block below
@@ -879,10 +898,10 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     }
 }
 
-// The walk's moves are a bit stream, 2 bits per move (1 diag, 2 up, 3 left), move t at bits 2t of the alignment's move words.
+// The walk's moves are a bit stream, 2 bits per move (3 diag, 2 up, 1 left), move t at bits 2t of the alignment's move words.
 // Position i of the ascending list is the sum of the deltas of moves total-2 .. total-1-i, so a wavefront expands 512
 // positions per trip: lane l takes the EIGHT moves of positions 8l .. 8l+7 of the chunk as one 16-bit field of the stream
-// (y steps = c1 xor c0, x steps = c0 of every 2-bit code: two masks), a 64-lane prefix sum of the lanes' popcounts places the
+// (y steps = c1, x steps = c0 of every 2-bit code: two masks), a 64-lane prefix sum of the lanes' popcounts places the
 // lane, and position k of the lane is the lane's base + popcount of the top k+1 fields -- two v_bcnt with an accumulator per
 // coordinate.  ~0.2 instructions per position (round 2: one position per lane and prefix sum, ~0.75: the kernel was bound by
 // instruction issue, 3.4 TB/s of stores).  The lanes' 64-byte results cross LDS so that every store instruction writes
@@ -917,7 +936,7 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
         unsigned f = s >= 0 ? (unsigned)(w >> ((2 * sc) & 31)) : (unsigned)w << up;
         const int lo = -s < 0 ? 0 : (-s > 8 ? 8 : -s), hi = total - 1 - s < 0 ? 0 : (total - 1 - s > 8 ? 8 : total - 1 - s);
         f &= ((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u);             // fields lo .. hi-1 hold moves 0 .. total-2
-        const unsigned yb = (f ^ (f >> 1)) & 0x5555u, xb = f & 0x5555u;       // a row step / a column step per move
+        const unsigned yb = (f >> 1) & 0x5555u, xb = f & 0x5555u;             // a row step / a column step per move
         // inclusive prefix sum of the lanes' totals (y in the low half, x in the high half: both stay below 2^15)
         const unsigned own = (unsigned)__popc(yb) | ((unsigned)__popc(xb) << 16);
         unsigned v = own;
