@@ -90,38 +90,64 @@ constexpr int kPkBase0 = 2 - kPkFloor;
 constexpr unsigned kPadSeq1 = 4u, kPadSeq2 = 5u;          // three bits: the match test ORs three bits of the XOR
 constexpr int kStreamWords = (kLen + 128) / 16;          // 16 fields per word; 128 fields of pad cover every read-ahead
 
+// 4 bytes -> 4 fields (16 bits): a byte that is no base scores as a mismatch against anything (source.cpp:1918-1920), which
+// is what a pad field does
+__device__ __forceinline__ unsigned sg_squeeze4(unsigned v, unsigned pad)
+{
+    const unsigned high = v & 0xFCFCFCFCu;                                          // nonzero in a byte: no base
+    const unsigned flag = (((high & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | high) & 0x80808080u;   // bit 7 of every such byte
+    const unsigned mask = flag | (flag - (flag >> 7));                              // 0xFF in every such byte
+    unsigned c = (v & 0x03030303u & ~mask) | ((pad * 0x01010101u) & mask);
+    c = (c | (c >> 4)) & 0x00FF00FFu;
+    return (c | (c >> 8)) & 0xFFFFu;
+}
+
+// One wavefront per TILE: 8 consecutive words (128 characters) of all 2A streams of one sweep block.  Eight lanes read one
+// 128-byte line of a sequence, the tile crosses LDS, and it leaves as one contiguous block of 8 * 2A words in 16-byte pieces
+// -- every line of the input is fetched once and every store instruction writes a contiguous kilobyte.  (One thread per output
+// word, rounds 1-2: the 16-byte reads of neighbouring threads lay 16 KB apart and every input line was requested by eight
+// different wavefronts; 1.3 ms at 65536 alignments.)
+constexpr int kPackWords = 8;                             // words per tile
+static_assert(kStreamWords % kPackWords == 0 && kLen / 16 % kPackWords == 0, "whole tiles; the pad words are a tile of their own");
 __global__ void __launch_bounds__(256)
 sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, uint32_t n,
-                       unsigned long long *__restrict__ streams, uint32_t per_block /* A: alignments per sweep wavefront */)
+                       unsigned long long *__restrict__ streams, uint32_t per_block /* A: alignments per sweep wavefront, 16 / 32 / 64 */)
 {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;              // one thread per output word
-    const uint32_t slots = 2 * per_block;
+    __shared__ unsigned long long tiles[4][kPackWords * (128 + 8)];          // [wavefront][word][slot], rows padded by 8 words
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t slots = 2 * per_block, pitch = slots + 8;                 // (the pitch keeps the 8-byte writes of a wavefront on distinct banks)
+    constexpr uint32_t kTiles = kStreamWords / kPackWords;
     const size_t n_blocks = ((size_t)n + per_block - 1) / per_block;
-    if (t >= n_blocks * kStreamWords * slots) return;
-    const uint32_t slot = (uint32_t)(t % slots);
-    const size_t rest = t / slots;
-    const uint32_t j = (uint32_t)(rest % kStreamWords);                   // characters 16 j .. 16 j + 15
-    const uint32_t a_full = (uint32_t)(rest / kStreamWords) * per_block + (slot >> 1);
-    const uint32_t a = a_full < n ? a_full : n - 1;                       // a ragged last block shadows the last alignment
-    const bool second = slot & 1u;                                        // 0: seq1, 1: seq2
-    unsigned long long out;
-    if (j < (uint32_t)(kLen / 16)) {
-        const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * j);
-        const unsigned pad = second ? kPadSeq2 : kPadSeq1;
-        auto squeeze = [pad](unsigned v) -> unsigned long long {          // 4 bytes -> 4 fields
-            unsigned r = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned b = (v >> (8 * k)) & 0xFFu;
-                r |= (b < 4u ? b : pad) << (4 * k);       // a byte that is no base scores as a mismatch against anything
-            }                                             // (source.cpp:1918-1920), which is what a pad field does
-            return (unsigned long long)r;
-        };
-        out = squeeze(b.x) | (squeeze(b.y) << 16) | (squeeze(b.z) << 32) | (squeeze(b.w) << 48);
-    } else {
-        out = (second ? kPadSeq2 : kPadSeq1) * 0x1111111111111111ull;
+    const size_t tile_id = (size_t)blockIdx.x * 4 + wv;
+    if (tile_id >= n_blocks * kTiles) return;                                 // wave-uniform
+    const uint32_t blk = (uint32_t)(tile_id / kTiles), tw = (uint32_t)(tile_id % kTiles);      // words 8 tw .. 8 tw + 7 of block blk
+    unsigned long long *out = streams + ((size_t)blk * kStreamWords + (size_t)kPackWords * tw) * slots;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    if (tw >= (uint32_t)(kLen / 16 / kPackWords)) {                           // past the sequences: pads (slot parity = which sequence)
+        const u64x2 pads = {kPadSeq1 * 0x1111111111111111ull, kPadSeq2 * 0x1111111111111111ull};
+        for (uint32_t p = lane; p < kPackWords * slots / 2; p += 64) *reinterpret_cast<u64x2 *>(out + 2 * p) = pads;
+        return;
     }
-    streams[t] = out;
+    unsigned long long *tile = tiles[wv];
+    const uint32_t word = lane & 7, group = lane >> 3;
+    for (uint32_t s0 = 0; s0 < slots; s0 += 8) {
+        const uint32_t slot = s0 + group;
+        const uint32_t a_full = blk * per_block + (slot >> 1);
+        const uint32_t a = a_full < n ? a_full : n - 1;                       // a ragged last block shadows the last alignment
+        const bool second = slot & 1u;                                        // 0: seq1, 1: seq2
+        const uint4 b = *reinterpret_cast<const uint4 *>((second ? seq2s : seq1s) + (size_t)a * kLen + 16 * (kPackWords * tw + word));
+        const unsigned pad = second ? kPadSeq2 : kPadSeq1;
+        tile[word * pitch + slot] = (unsigned long long)(sg_squeeze4(b.x, pad) | (sg_squeeze4(b.y, pad) << 16)) |
+                                    ((unsigned long long)(sg_squeeze4(b.z, pad) | (sg_squeeze4(b.w, pad) << 16)) << 32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t p = lane; p < kPackWords * slots / 2; p += 64) {            // 16-byte piece p = words 2p, 2p + 1 of the output block
+        const uint32_t w = 2 * p / slots, sl = 2 * p % slots;
+        const u64x2 v = {tile[w * pitch + sl], tile[w * pitch + sl + 1]};
+        *reinterpret_cast<u64x2 *>(out + 2 * p) = v;
+    }
 }
 
 // ---- packed 16-bit helpers of the split and lane sweeps ----------------------------------------------------------
@@ -1059,8 +1085,8 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     const int sweep = choose_sweep(n, compute_units, tuning);
     {
         const uint32_t per_block = 64 / sweep_lanes(sweep);                 // alignments per sweep wavefront: 64 / G
-        const size_t words = ((n + per_block - 1) / per_block) * (size_t)kStreamWords * 2 * per_block;
-        hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_seq1s, d_seq2s,
+        const size_t tiles = ((n + per_block - 1) / per_block) * (size_t)(kStreamWords / kPackWords);        // one wavefront each
+        hipLaunchKernelGGL(sg_pack_streams_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, d_seq1s, d_seq2s,
                            (uint32_t)n, streams, per_block);
         const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32)), grid1((unsigned)((n + 63) / 64));
 #define SWMI_SG_LAUNCH1(W) \
