@@ -352,6 +352,20 @@ def sg_traffic(P, kernel, code_sha):
     return None, None
 
 
+def sg_sweep_shape(kernel_name):
+    """(alignments per wavefront, census marker) of a semi-global sweep kernel as swmi_semiglobal_kernels_for_batch names it:
+    64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes; the sweeps' round loop is unrolled by two and the
+    X-drop test's one v_pk_ashrrev_i16 per register (two cells) marks a round."""
+    name = kernel_name.replace(" ", "")
+    if name.startswith("sg_forward_lane_kernel<"):
+        return 64, ("v_pk_ashrrev_i16", 16)
+    if name.startswith("sg_forward_split_kernel<2,"):
+        return 32, ("v_pk_ashrrev_i16", 8)
+    if name.startswith("sg_forward_split_kernel<4,"):
+        return 16, ("v_pk_ashrrev_i16", 4)
+    raise ValueError("unknown semi-global sweep kernel %r" % kernel_name)
+
+
 def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None):
     """Secondary row: the reference's semi-global adaptive-band X-drop aligner incl. traceback (single GPU).
     Inputs follow SpeedtestSemiGlobal (source.cpp:2805-2813): a random 16384-mer and a copy with 5 % substitutions."""
@@ -404,13 +418,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     alg_bytes = P * (2 * L + 8) + int(lengths.to(torch.int64).sum().item()) * 8
     sweep_kernel, tb_kernel = swmi.semiglobal_kernels_for_batch(P)          # the library says which mapping it ran
     name = sweep_kernel.replace(" ", "")
-    # wavefronts of the sweep: 64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes, 2 with a band per half-wavefront
-    family = name.split(",")[0]
-    per_wave = {"sg_forward_lane_kernel<1": 64, "sg_forward_lane_kernel<2": 64, "sg_forward_lane_kernel<3": 64, "sg_forward_lane_kernel<4": 64,
-                "sg_forward_split_kernel<2": 32, "sg_forward_split_kernel<4": 16}.get(family, 2)
-    # the sweeps' round loop is unrolled by two; the X-drop test's one v_pk_ashrrev_i16 per register (two cells) marks a round
-    marker = ("v_pk_ashrrev_i16", 16) if family.startswith("sg_forward_lane_kernel") else \
-        {"sg_forward_split_kernel<2": ("v_pk_ashrrev_i16", 8), "sg_forward_split_kernel<4": ("v_pk_ashrrev_i16", 4)}.get(family)
+    per_wave, marker = sg_sweep_shape(name)
     # the record flush + stream top-up block runs on every 16th round; the loop holds two rounds and hipcc keeps one copy
     # of the block behind each, so of the conditional instructions the census finds in a trip 1/16 run on average
     roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker, conditional_share=1.0 / 16)
