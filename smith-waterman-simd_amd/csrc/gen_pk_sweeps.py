@@ -132,7 +132,7 @@ def section(variant, R):
             o.append('    register uint32_t pk_d%d asm("s%d") = pk_dval(%d);' % (r, D0 + r, r))
     else:
         o.append("    const uint32_t pk_g2 = (uint32_t)gap | ((uint32_t)gap << 16);")
-    o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0, pk_up0 = 0;")
+    o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0%s;" % (", pk_up0 = 0" if variant == 2 else ""))
     o.append("    uint32_t pk_u0 = 0, pk_u1 = 0;          // H(last row of the lane before): this step's column / the previous one, alternating")
     o.append("    uint32_t pk_x0, pk_y0;")
     o.append("    tables_at(0, pk_x0, pk_y0);")

@@ -346,7 +346,7 @@ sw128_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2
 // 32-bit FULL-RATE v_add_u32 on the packed pair -- no half ever carries into the other -- instead of a second saturating
 // packed subtraction for t.  When every s + gap is already >= 0 -- (1,-1,1), the parameters of SmithWaterman_8bit111simd /
 // _8b111x32 (source.cpp:1105-1522), are the model case -- Q = 0, the two copies are one and the "+ Q" disappears
-// (BIAS = false).
+// (VARIANT kPkQ0).
 //   * one VGPR holds the SAME row of TWO alignments (low / high half), so there is no dependency inside a pair and the
 //     two alignments share every instruction; a lane group of L lanes walks two alignments (L = 4: a wavefront 32);
 //   * score lookup for both halves = ONE v_perm_b32: its 8 source bytes are the score tables of the CURRENT COLUMN of
@@ -494,7 +494,6 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
                 uint32_t n, SmRows rows /* s + gap + Q (kPkVert: s + 2 gap), every byte in [0, 255] */, int gap, int q)
 {
     static_assert(L == 4 || L == 8 || L == 16, "lanes per pair of alignments");
-    constexpr bool BIAS = VARIANT == kPkBias;
     constexpr bool kGenerated = VARIANT == kPkQ0 || VARIANT == kPkVert;
     constexpr int R = kSeqLen / L;          // rows per lane (L = lanes per pair of alignments)
     constexpr int G = 64 / L;               // lane groups per wavefront, each walking TWO alignments
@@ -578,7 +577,7 @@ sw128_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ s
     //                          t = H(i-1,j-1) + (s + gap + Q) non-negative without a second saturating subtraction)
     //   hu[i] = H(row i)       what the diagonal term starts from
     // Adding Q is a plain 32-bit add on the packed pair: every half stays in [0, 0x7C00), so nothing carries from the low half
-    // into the high one.  With Q = 0 (BIAS = false) the two copies are one.
+    // into the high one.  (Q = 0 is VARIANT kPkQ0: one copy, the generated sweep.)
     const uint32_t gq2 = (uint32_t)(gap + q) | ((uint32_t)(gap + q) << 16);
     const uint32_t q2 = (uint32_t)q | ((uint32_t)q << 16);
     uint32_t best = 0;
