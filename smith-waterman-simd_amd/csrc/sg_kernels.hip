@@ -30,8 +30,8 @@ constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
 // lines of one window lie side by side for all alignments of the batch:
 //     record of (alignment a, round r) = uint2 index ((r / 16) * n + a) * 16 + (r % 16)
 // Sweeps and walks move through the rounds in lockstep -- every alignment of a wavefront is in the same window at the same
-// time -- so a sweep wavefront's flush (its 32 alignments) and a walk wavefront's fetch (its 64 walks) are ONE contiguous
-// 4 / 8 KB block, written and read with fully coalesced 16-byte accesses.  (Round 2 kept one array per alignment: a walk
+// time -- so a sweep wavefront's flush (its 16 / 32 / 64 alignments) and a walk wavefront's fetch (its 64 walks) are ONE
+// contiguous block of 2 .. 8 KB, written and read with fully coalesced 16-byte accesses.  (Round 2 kept one array per alignment: a walk
 // wavefront's fetch was 64 separate lines 262 KB apart, each requested in 16-byte pieces by one lane: 3.5 TB/s.)
 constexpr int kCodeWindow = 16;                           // rounds per line
 constexpr int kCodeWindows = (kMaxRound + kCodeWindow - 1) / kCodeWindow;
@@ -45,7 +45,7 @@ constexpr int kDirWords = kMaxRound / 32 + 1;
 // Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
 // three-way max: 3 diagonal, 2 up, 1 left (0: round 0 / nothing) -- the reference's tie-break order (source.cpp:1962-1971)
 // falls out of comparing equal values by tag -- band cell k at bits 2k..2k+1 of the round's 64 bits.
-// The traceback's move code: 1 diagonal, 2 up, 3 left = (4 - tag) & 3.
+// The walk hands the tags on as its moves; the expand kernel reads a row step off bit 1 and a column step off bit 0.
 __device__ __forceinline__ unsigned record_tag(uint2 cw, int bl)
 {
     return (unsigned)((((unsigned long long)cw.y << 32) | cw.x) >> (2 * bl)) & 3u;
@@ -149,6 +149,53 @@ sg_pack_streams_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restr
         *reinterpret_cast<u64x2 *>(out + 2 * p) = v;
     }
 }
+
+// One sequence's character stream of one alignment (the format sg_pack_streams_kernel writes), read 16 characters ahead:
+//   sreg   the next 16 characters (the next one at bit used4: a consume only advances used4), pend: the characters after
+//   those (p_fill of them, low-aligned, zeros above), ahead: the word after pend (a load issued at the previous top-up),
+//   w_next: index of the word after `ahead`.
+// top_up() runs every 16 rounds -- a stream gives at most 16 characters in 16 rounds -- at the same place for every lane, so
+// the round itself holds no load and no wait.  (With the refill inside the round hipcc kept the prefetched word in a register
+// pair of its own and copied it every round, which put an s_waitcnt vmcnt(0) -- on the load AND on the record stores -- into
+// every round.)
+struct SgStream {
+    const unsigned long long *words;                      // word w of the stream at words[w * stride]
+    unsigned long long sreg, pend, ahead;
+    int p_fill, w_next, used4;
+    __device__ __forceinline__ void start(const unsigned long long *w, size_t stride, int first_char)
+    {
+        words = w;
+        const int c0 = first_char & 15, w0i = first_char >> 4;
+        const unsigned long long w0 = words[w0i * stride], w1 = words[(w0i + 1) * stride];
+        sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
+        pend = w1 >> (4 * c0);
+        p_fill = 16 - c0;
+        ahead = words[(w0i + 2) * stride];
+        w_next = w0i + 3;
+        used4 = 0;
+    }
+    __device__ __forceinline__ unsigned next() const { return (unsigned)(sreg >> used4) & 15u; }
+    __device__ __forceinline__ void top_up(size_t stride)
+    {
+        const int k = used4 >> 2;
+        sreg = k < 16 ? sreg >> used4 : 0ull;
+        used4 = 0;
+        const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
+        const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;           // pend's characters behind the 16 - k left
+        const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
+        sreg |= add_p | add_a;
+        if (rem > 0 || from_pend == p_fill) {                                       // pend is used up: `ahead` becomes pend
+            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
+            p_fill = 16 - rem;
+            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;         // a band that has left the matrix keeps stepping
+            ahead = words[(size_t)w * stride];
+            ++w_next;
+        } else {
+            pend = from_pend ? pend >> (4 * from_pend) : pend;
+            p_fill -= from_pend;
+        }
+    }
+};
 
 // ---- packed 16-bit helpers of the split and lane sweeps ----------------------------------------------------------
 // Two band cells per register.  Every half is an integer in [0, 0x7C00): as bit patterns those are the non-negative finite
@@ -314,47 +361,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     if (is_first) stage_codes[al][0] = make_uint2(0, 0);
     // This lane's character stream: the first slice feeds on seq1 (consumed when the band steps down), the last slice on
     // seq2 (consumed when it steps right); slices in between run the seq1 stream along without using it.
-    //   sreg   the next 16 characters, next one in the low field; a consume shifts it by one field (zeros come in)
-    //   pend   characters after those (p_fill of them, low-aligned, zeros above), ahead: the word after pend (a load
-    //          issued at the previous top-up), w_next: index of the word after `ahead`
-    // Every 16 rounds -- a lane consumes at most 16 characters in 16 rounds -- one block, at the same place for every lane,
-    // tops sreg up to 16 characters again from pend / ahead and requests the next word.  The round loop itself holds no
-    // load and no wait: with the refill inside the round, hipcc keeps the prefetched word in a register pair of its own
-    // and copies it every round, which puts an s_waitcnt vmcnt(0) -- on the load AND on the record stores -- into every round.
-    const unsigned long long *my_stream = is_last ? stream_b : stream_a;
-    unsigned long long sreg, pend, ahead;
-    int p_fill, w_next, used4 = 0;                        // used4 = 4 * characters consumed since the last top-up
-    {
-        const int s_idx = is_last ? 0 : 31;               // next character: seq2[0] / seq1[31]
-        const int c0 = s_idx & 15, w0i = s_idx >> 4;
-        const unsigned long long w0 = my_stream[w0i * kStreamStride], w1 = my_stream[(w0i + 1) * kStreamStride];
-        sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
-        pend = w1 >> (4 * c0);
-        p_fill = 16 - c0;
-        ahead = my_stream[(w0i + 2) * kStreamStride];
-        w_next = w0i + 3;
-    }
-    auto top_up = [&]() {                                 // used4 / 4 characters consumed since the last call: refill sreg to 16
-        const int k = used4 >> 2;
-        sreg = k < 16 ? sreg >> used4 : 0ull;             // (between top-ups the round reads its character at bit used4: no shift per round)
-        used4 = 0;
-        const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
-        // pend's first `from_pend` characters go behind the 16 - k that are left; whatever of pend does not fit falls off the top
-        const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;
-        const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
-        sreg |= add_p | add_a;
-        const bool crossed = rem > 0 || from_pend == p_fill;                         // pend is used up: `ahead` becomes pend
-        if (crossed) {
-            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
-            p_fill = 16 - rem;
-            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;          // a band that has left the matrix keeps stepping: stay inside the stream
-            ahead = my_stream[(size_t)w * kStreamStride];
-            ++w_next;
-        } else {
-            pend = from_pend ? pend >> (4 * from_pend) : pend;
-            p_fill -= from_pend;
-        }
-    };
+    SgStream feed;
+    feed.start(is_last ? stream_b : stream_a, kStreamStride, is_last ? 0 : 31);       // next character: seq2[0] / seq1[31]
 
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
     auto one_round = [&](const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
@@ -375,7 +383,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const int hi_in = (int)__builtin_amdgcn_alignbit(p_hi, (unsigned)cur[0], 16);            // (cell NV, cell C)
         // sequence windows follow the band
         {
-            const unsigned cand = (unsigned)(sreg >> used4) & 15u;            // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
+            const unsigned cand = feed.next();            // the character entering: seq1[pos_y + 30] or seq2[pos_x - 32], pads included
             const unsigned a_top = (unsigned)(aw >> (4 * C - 4)), b_low = (unsigned)bw & 15u;
             // (the DPP moves are evaluated by ALL lanes before the select: inside one arm of `?:` they would run with the
             // source lanes masked off)
@@ -388,7 +396,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             aw = (aw << shift_a) | (win_t)(a_in & ~(unsigned)rmask);
             bw = (bw >> shift_b) | ((win_t)(b_in & (unsigned)rmask) << (4 * C - 4));
             const int cmask = keep_opaque(~(rmask ^ last_mask));              // consume = is_last ? right : !right
-            used4 += cmask & 4;
+            feed.used4 += cmask & 4;
         }
         // a field of aw ^ bw is 0..7 (the codes have three bits): bit 0 of  z | z >> 1 | z >> 2  = "the characters differ"
         const win_t z = aw ^ bw;
@@ -482,7 +490,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
         if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
             flush_codes(round >> 4);
-            top_up();
+            feed.top_up(kStreamStride);
             if ((round & 31) == 31) {
                 if (real && is_first) *my_dirs = dir_word;
                 my_dirs += n;
@@ -524,49 +532,6 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
 // cells (direction, windows, match bits, best / threshold bookkeeping: ~80 instructions) is paid once per 64 alignments
 // instead of once per 32, so a batch that still gives every SIMD two or more of these wavefronts runs a third faster.
 // Register k = cells k (low half) and k + 16 (high half); the windows are 2 x 64 bits per sequence.
-
-// One sequence's character stream of one alignment (the format sg_pack_streams_kernel writes), read 16 characters ahead:
-//   sreg   the next 16 characters (the next one at bit used4), pend: the characters after those (p_fill of them, low-aligned,
-//   zeros above), ahead: the word after pend (a load issued at the previous top-up), w_next: index of the word after `ahead`.
-// top_up() runs every 16 rounds -- a stream gives at most 16 characters in 16 rounds -- so the round itself holds no load.
-struct SgStream {
-    const unsigned long long *words;                      // word w of the stream at words[w * stride]
-    unsigned long long sreg, pend, ahead;
-    int p_fill, w_next, used4;
-    __device__ __forceinline__ void start(const unsigned long long *w, size_t stride, int first_char)
-    {
-        words = w;
-        const int c0 = first_char & 15, w0i = first_char >> 4;
-        const unsigned long long w0 = words[w0i * stride], w1 = words[(w0i + 1) * stride];
-        sreg = c0 ? (w0 >> (4 * c0)) | (w1 << (64 - 4 * c0)) : w0;
-        pend = w1 >> (4 * c0);
-        p_fill = 16 - c0;
-        ahead = words[(w0i + 2) * stride];
-        w_next = w0i + 3;
-        used4 = 0;
-    }
-    __device__ __forceinline__ unsigned next() const { return (unsigned)(sreg >> used4) & 15u; }
-    __device__ __forceinline__ void top_up(size_t stride)
-    {
-        const int k = used4 >> 2;
-        sreg = k < 16 ? sreg >> used4 : 0ull;
-        used4 = 0;
-        const int from_pend = k < p_fill ? k : p_fill, rem = k - from_pend;
-        const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;           // pend's characters behind the 16 - k left
-        const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
-        sreg |= add_p | add_a;
-        if (rem > 0 || from_pend == p_fill) {                                       // pend is used up: `ahead` becomes pend
-            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
-            p_fill = 16 - rem;
-            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;         // a band that has left the matrix keeps stepping
-            ahead = words[(size_t)w * stride];
-            ++w_next;
-        } else {
-            pend = from_pend ? pend >> (4 * from_pend) : pend;
-            p_fill -= from_pend;
-        }
-    }
-};
 
 template <int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
@@ -1105,7 +1070,6 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
         case 11: SWMI_SG_LAUNCH1(1); break;
         case 12: SWMI_SG_LAUNCH1(2); break;
         case 13: SWMI_SG_LAUNCH1(3); break;
-        case 14: SWMI_SG_LAUNCH1(4); break;
         default: return hipErrorInvalidValue;
         }
 #undef SWMI_SG_LAUNCH

@@ -845,9 +845,9 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
 
 int swmi_semiglobal_set_mapping(int sweep)
 {
-    const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 14) ||
+    const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 13) ||
                           (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44);
-    if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..14, 21..24 or 41..44", sweep);
+    if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..13, 21..24 or 41..44", sweep);
     sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)));
     return SWMI_OK;
 }

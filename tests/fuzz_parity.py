@@ -98,7 +98,7 @@ while time.time() < t_end:
     for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
         cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
-    swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 24, 11, 12, 13, 14)[sg_iter % 12])
+    swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 24, 11, 12, 13)[sg_iter % 11])
     sg_iter += 1
     scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
     with ThreadPoolExecutor(workers) as ex:
