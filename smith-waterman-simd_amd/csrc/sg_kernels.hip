@@ -105,8 +105,8 @@ __device__ __forceinline__ unsigned sg_squeeze4(unsigned v, unsigned pad)
 // One wavefront per TILE: 8 consecutive words (128 characters) of all 2A streams of one sweep block.  Eight lanes read one
 // 128-byte line of a sequence, the tile crosses LDS, and it leaves as one contiguous block of 8 * 2A words in 16-byte pieces
 // -- every line of the input is fetched once and every store instruction writes a contiguous kilobyte.  (One thread per output
-// word, rounds 1-2: the 16-byte reads of neighbouring threads lay 16 KB apart and every input line was requested by eight
-// different wavefronts; 1.3 ms at 65536 alignments.)
+// word, the earlier form: the 16-byte reads of neighbouring threads lay 16 KB apart and every input line was requested by eight
+// different wavefronts; 1.3 ms at 65536 alignments with 128 streams interleaved.)
 constexpr int kPackWords = 8;                             // words per tile
 static_assert(kStreamWords % kPackWords == 0 && kLen / 16 % kPackWords == 0, "whole tiles; the pad words are a tile of their own");
 __global__ void __launch_bounds__(256)
