@@ -352,6 +352,13 @@ def sg_traffic(P, kernel, code_sha):
     return None, None
 
 
+def arith_dtype(kernel_name):
+    """The arithmetic type a kernel computes in (the line's `dtype`): the packed scorer and the semi-global sweeps work on
+    unsigned 16-bit halves of 32-bit registers (scores leave as int32), the other kernels on int32."""
+    k = (kernel_name or "").replace(" ", "")
+    return "u16" if k.startswith(("sw128_pk_kernel", "sg_forward_")) else "int32"
+
+
 def sg_sweep_shape(kernel_name):
     """(alignments per wavefront, census marker) of a semi-global sweep kernel as swmi_semiglobal_kernels_for_batch names it:
     64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes; the sweeps' round loop is unrolled by two and the
@@ -400,7 +407,7 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     value = P * steps / elapsed
     line = {"metric": "alignments/sec, semi-global adaptive-band X-drop with traceback (SURVEY 8f N4)", "value": round(value, 1),
             "unit": "alignments/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(elapsed * 1e3 / steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "SemiGlobal_AdaptiveBanded_XDrop_111_32_70 (source.cpp:1836): %d pairs of 16384-mers, 5 %% "
                                    "substitutions (SpeedtestSemiGlobal inputs), band 32, X-drop 70, score + full traceback, "
                                    "inputs resident in HBM" % P},
@@ -605,7 +612,7 @@ def single_gpu(args, swmi, np, torch, local_rank):
         "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
         "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
-        "dtype": "int32", "data": "synthetic",
+        "dtype": arith_dtype(roof.get("kernel")), "data": "synthetic",
         "gcups": round(value * CELLS / 1e9, 1),
         "config": {"workload": "%s: %d random 128x128 pairs per GPU per step, sm %d/%d gap %d, inputs resident in HBM, int32 scores" % (
                        {"pairs": "BASELINE.json configs[1]", "packed": "SURVEY 8f N3 (2-bit packed inputs, source.cpp:1581)",
@@ -859,7 +866,7 @@ def multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank):
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(head["value"] / REFERENCE_PUBLISHED_ALIGN_PER_S, 1),
             "baseline_note": "reference README.md:4: simd4 ~4.4 s / 1M calls on one EPYC 7501 core (227k alignments/s)",
-            "dtype": "int32", "data": "synthetic", "gcups": round(head["value"] * CELLS / 1e9, 1),
+            "dtype": arith_dtype(roof.get("kernel")), "data": "synthetic", "gcups": round(head["value"] * CELLS / 1e9, 1),
             "config": {"workload": "BASELINE.json configs[3] shape: %d random 128x128 pairs per GPU per step (%d in all), sm %d/%d gap %d, "
                                    "inputs resident in HBM (generated on each GPU from the global pair index), int32 scores, RCCL "
                                    "all-gather of the scores after every step, overlapped with the next step's kernel" % (
