@@ -18,7 +18,8 @@ Sections (selected with PK_SECTION = 100 * variant + rows per lane before includ
                     max3 result as it is, the dependency chain is max3 -> max3 -- and the diagonal term is
                     L_{r-1} + (score + 2 gap), never negative, with L_r = H_r + D_r.  Off the chain: H_r = x_r -sat (gap + D_r)
                     (exact floor at 0: what the diagonal and the running best need), L = H + D as a paired 64-bit add.
-                    Lanes hand each other H itself (exact), so row 0 adds D_0 to what it takes as `up` (one add per step).
+                    Lanes hand each other H itself (exact), so row 0 adds D_0 to what it takes as `up`: that addition and row 0's
+                    diagonal term share one paired add.
                     Per two rows: 2 v_perm, 2 max3, 2 sat-sub, 2 paired adds, 1 max3 (best) = 9 instructions (round 2's
                     bias form: 11).  Pad columns look up 0, i.e. act as score -2 gap: harmless (kernel header).
 The code expects, in the including scope: `col` (per-column table offsets), `tables_at(t, cx, cy)`, `rsel[R]`, `group_mask`,
@@ -55,17 +56,31 @@ def step(variant, R, cx, cy, up, diag, out):
             return
         dst = "pk_s0" if i == 0 else sc((i - 1) // 2, (i - 1) % 2)
         emit(c, "v_perm_b32 %0, %1, %2, %3", [dst], [cy, cx, "rsel[%d]" % i])
-    P(0)
-    emit(c, "v_add_u32 %0, %1, %2", ["pk_t0"], [diag, "pk_s0"])
-    P(1)
-    if variant == 2:     # the lane before hands over H itself; as an input of row 0's max3 it stands in domain D_0: + gap
-        emit(c, "v_add_u32 %0, %2, %1", ["pk_up0"], [up], ["pk_d0"])
-        up = "pk_up0"
+    t0 = "pk_t0"
+    if variant == 2:
+        # Row 0's two additions -- the diagonal term  diag + score  and, because the lane before hands over H itself, `up` + D_0
+        # (row 0's max3 runs in domain D_0) -- are ONE v_lshl_add_u64: the two hand-over values live in the aligned pair
+        # v[30:31] (pk_u0, pk_u1; which of them is this step's `up` alternates), the addend pair is (D_0, score) or
+        # (score, D_0) accordingly, the sums land in v[28:29].
+        first = up == "pk_u0"                              # v30 is `up`: addends (D_0, score) = v[26:27]; else (score, D_0) = v[14:15]
+        s0 = "pk_sA" if first else "pk_sB"
+        emit(c, "v_perm_b32 %0, %1, %2, %3", [s0], [cy, cx, "rsel[0]"])
+        P(1)
+        if first:
+            emit(c, "v_lshl_add_u64 v[28:29], v[30:31], 0, v[26:27]", ["pk_ta", "pk_tb"], ["pk_u0", "pk_u1", "pk_dA", "pk_sA"])
+            up, t0 = "pk_ta", "pk_tb"
+        else:
+            emit(c, "v_lshl_add_u64 v[28:29], v[30:31], 0, v[14:15]", ["pk_ta", "pk_tb"], ["pk_u0", "pk_u1", "pk_sB", "pk_dB"])
+            up, t0 = "pk_tb", "pk_ta"
+    else:
+        P(0)
+        emit(c, "v_add_u32 %0, %1, %2", ["pk_t0"], [diag, "pk_s0"])
+        P(1)
     P(2)
     nblk = R // 2
     for k in range(nblk):
         a, b = 2 * k, 2 * k + 1
-        t_a = "pk_t0" if k == 0 else "pk_tt1"
+        t_a = t0 if k == 0 else "pk_tt1"
         last = b + 1 >= R
         if variant == 0:
             emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_xa"], [h(a), up if k == 0 else h(a - 1), t_a])
@@ -132,8 +147,16 @@ def section(variant, R):
             o.append('    register uint32_t pk_d%d asm("s%d") = pk_dval(%d);' % (r, D0 + r, r))
     else:
         o.append("    const uint32_t pk_g2 = (uint32_t)gap | ((uint32_t)gap << 16);")
-    o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0%s;" % (", pk_up0 = 0" if variant == 2 else ""))
-    o.append("    uint32_t pk_u0 = 0, pk_u1 = 0;          // H(last row of the lane before): this step's column / the previous one, alternating")
+    if variant == 2:
+        o.append("    uint32_t pk_xa = 0, pk_xb = 0;")
+        o.append('    register uint32_t pk_u0 asm("v30") = 0, pk_u1 asm("v31") = 0;   // H(last row of the lane before): this step\'s column / the previous one, alternating')
+        o.append('    register uint32_t pk_ta asm("v28") = 0, pk_tb asm("v29") = 0;   // row 0: `up` + D_0 and the diagonal term, in the order of (pk_u0, pk_u1)')
+        o.append('    register uint32_t pk_dA asm("v26") = pk_dval(0), pk_sA asm("v27") = 0;   // addends (D_0, score of row 0)')
+        o.append('    register uint32_t pk_sB asm("v14") = 0, pk_dB asm("v15") = pk_dval(0);   // addends (score of row 0, D_0)')
+        o.append('    asm volatile("" : "+v"(pk_dA), "+v"(pk_dB));      // opaque: or hipcc re-creates the two constants from the scalar D_0 every step')
+    else:
+        o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0;")
+        o.append("    uint32_t pk_u0 = 0, pk_u1 = 0;          // H(last row of the lane before): this step's column / the previous one, alternating")
     o.append("    uint32_t pk_x0, pk_y0;")
     o.append("    tables_at(0, pk_x0, pk_y0);")
     o.append("    for (int t2 = 0; t2 < T2; ++t2) {")
