@@ -12,7 +12,7 @@ what is read and written.  Every statement is `asm volatile`: they are issued in
 Sections (selected with PK_SECTION = 100 * variant + rows per lane before including the file inside the kernel body):
   variant 0 "q0"    every score + gap >= 0.  Per two rows: 2 v_perm (lookup), 1 v_lshl_add_u64 (both diagonal terms),
                     2 v_pk_maximum3_f16, 2 v_pk_sub_u16 clamp, 1 v_pk_maximum3_f16 (running best) = 8 instructions
-                    (round 2: 9).
+                    (round 2: 9).  Rows 0 and R - 1, whose diagonal terms have no neighbour row, share a paired add too.
   variant 2 "vert"  some score + gap < 0 but every score + 2 gap >= 0.  Row r of a lane works in its own domain
                     D_r = gap * (r + 1): the value handed down the column then needs no subtraction -- `up` is the row above's
                     max3 result as it is, the dependency chain is max3 -> max3 -- and the diagonal term is
@@ -47,11 +47,16 @@ def step(variant, R, cx, cy, up, diag, out):
     """code of one anti-diagonal step: column tables cx / cy, `up` / `diag` from the lane before, hand-over value -> out"""
     c = []
     h = lambda r: "pk_h%d" % r
+    # q0: row R - 2 alternates between two registers from step to step (each sits below one of the two hand-over registers,
+    # see below): hr = the name a step reads (the previous step's value), hw = the name it writes
+    q0_first = variant == 0 and diag == "pk_u1"
+    hr = lambda r: ("pk_hpA" if q0_first else "pk_hpB") if variant == 0 and r == R - 2 else h(r)
+    hw = lambda r: ("pk_hpB" if q0_first else "pk_hpA") if variant == 0 and r == R - 2 else h(r)
     sc = lambda k, half: "pk_sc%d" % (2 * (k % 2) + half)
     sc_reg = lambda k: SC[k % 2]
     # score lookups: row 0 into an ordinary register, row i >= 1 into its half of SC_{(i-1)//2}
     def P(i):
-        if i >= R:
+        if i >= R or (variant == 0 and i == R - 1):        # (q0 looks the last row up at the start of the step)
             c.append('    asm volatile("s_nop 0");')
             return
         dst = "pk_s0" if i == 0 else sc((i - 1) // 2, (i - 1) % 2)
@@ -73,9 +78,15 @@ def step(variant, R, cx, cy, up, diag, out):
             emit(c, "v_lshl_add_u64 v[28:29], v[30:31], 0, v[14:15]", ["pk_ta", "pk_tb"], ["pk_u0", "pk_u1", "pk_sB", "pk_dB"])
             up, t0 = "pk_tb", "pk_ta"
     else:
-        P(0)
-        emit(c, "v_add_u32 %0, %1, %2", ["pk_t0"], [diag, "pk_s0"])
+        # The two diagonal terms that have no neighbour row to pair with -- row 0's (hand-over value + score) and the last
+        # row's (row R - 2 of the previous column + score) -- are ONE v_lshl_add_u64: row R - 2 and the hand-over value sit in
+        # an aligned pair, v[H0+R-2 : H0+R-1] in one step and v[H0+R+2 : H0+R+3] in the next (both alternate), the two looked-up
+        # scores in v[26:27], the sums land in v[28:29].
+        pair = H0 + R - 2 if q0_first else H0 + R + 2
+        emit(c, "v_perm_b32 %0, %1, %2, %3", ["pk_s0"], [cy, cx, "rsel[0]"])
+        emit(c, "v_perm_b32 %0, %1, %2, %3", ["pk_sL"], [cy, cx, "rsel[%d]" % (R - 1)])
         P(1)
+        emit(c, "v_lshl_add_u64 v[28:29], v[%d:%d], 0, v[26:27]" % (pair, pair + 1), ["pk_ttL", "pk_t0"], [hr(R - 2), diag, "pk_sL", "pk_s0"])
     P(2)
     nblk = R // 2
     for k in range(nblk):
@@ -83,15 +94,15 @@ def step(variant, R, cx, cy, up, diag, out):
         t_a = t0 if k == 0 else "pk_tt1"
         last = b + 1 >= R
         if variant == 0:
-            emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_xa"], [h(a), up if k == 0 else h(a - 1), t_a])
+            emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_xa"], [hr(a), up if k == 0 else h(a - 1), t_a])
             if not last:
                 emit(c, "v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (TT, TT + 1, H0 + a, H0 + b, sc_reg(k), sc_reg(k) + 1),
                      ["pk_tt0", "pk_tt1"], [h(a), h(b), sc(k, 0), sc(k, 1)])
             else:
-                emit(c, "v_add_u32 %0, %1, %2", ["pk_tt0"], [h(a), sc(k, 0)])
-            emit(c, "v_pk_sub_u16 %0, %1, %2 clamp", [h(a)], ["pk_xa"], ["pk_g2"])
+                c.append('    asm volatile("s_nop 0");')     # (the last row's diagonal term came with row 0's)
+            emit(c, "v_pk_sub_u16 %0, %1, %2 clamp", [hw(a)], ["pk_xa"], ["pk_g2"])
             P(b + 2)
-            emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_xb"], [h(b), h(a), "pk_tt0"])
+            emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_xb"], [h(b), hw(a), "pk_ttL" if last else "pk_tt0"])
             P(b + 3)
             emit(c, "v_pk_sub_u16 %0, %1, %2 clamp", [h(b)], ["pk_xb"], ["pk_g2"])
             emit(c, "v_pk_maximum3_f16 %0, %1, %2, %3", ["pk_best"], ["pk_best", "pk_xa", "pk_xb"])
@@ -136,7 +147,12 @@ def section(variant, R):
     o.append("    // ---- generated by gen_pk_sweeps.py: %s cell, %d rows per lane ----" % ("q0" if variant == 0 else "vertical-offset", R))
     for r in range(R):
         init = "0" if variant == 0 else "pk_dval(%d)" % r
-        o.append('    register uint32_t pk_h%d asm("v%d") = %s;' % (r, H0 + r, init))
+        if variant == 0 and r == R - 2:
+            o.append('    register uint32_t pk_hpA asm("v%d") = 0, pk_hpB asm("v%d") = 0;   // row %d, alternating by step' % (H0 + R - 2, H0 + R + 2, r))
+        elif variant == 0 and r == R - 1:
+            o.append('    register uint32_t pk_h%d asm("v%d") = 0;' % (r, H0 + R))
+        else:
+            o.append('    register uint32_t pk_h%d asm("v%d") = %s;' % (r, H0 + r, init))
     for q in range(4):
         o.append('    register uint32_t pk_sc%d asm("v%d") = 0;' % (q, SC[0] + q))
     o.append('    register uint32_t pk_tt0 asm("v%d") = 0, pk_tt1 asm("v%d") = 0;' % (TT, TT + 1))
@@ -155,8 +171,10 @@ def section(variant, R):
         o.append('    register uint32_t pk_sB asm("v14") = 0, pk_dB asm("v15") = pk_dval(0);   // addends (score of row 0, D_0)')
         o.append('    asm volatile("" : "+v"(pk_dA), "+v"(pk_dB));      // opaque: or hipcc re-creates the two constants from the scalar D_0 every step')
     else:
-        o.append("    uint32_t pk_xa = 0, pk_xb = 0, pk_t0 = 0, pk_s0 = 0;")
-        o.append("    uint32_t pk_u0 = 0, pk_u1 = 0;          // H(last row of the lane before): this step's column / the previous one, alternating")
+        o.append("    uint32_t pk_xa = 0, pk_xb = 0;")
+        o.append('    register uint32_t pk_u1 asm("v%d") = 0, pk_u0 asm("v%d") = 0;   // H(last row of the lane before): this step\'s column / the previous one, alternating; each above one copy of row %d' % (H0 + R - 1, H0 + R + 3, R - 2))
+        o.append('    register uint32_t pk_sL asm("v26") = 0, pk_s0 asm("v27") = 0;   // scores of the last row and of row 0')
+        o.append('    register uint32_t pk_ttL asm("v28") = 0, pk_t0 asm("v29") = 0;  // their diagonal terms')
     o.append("    uint32_t pk_x0, pk_y0;")
     o.append("    tables_at(0, pk_x0, pk_y0);")
     o.append("    for (int t2 = 0; t2 < T2; ++t2) {")
