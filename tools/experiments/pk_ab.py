@@ -20,6 +20,6 @@ for n in (1 << 20, 1 << 24):
     res.append("%d pairs %.4f ms (%.2f us per 1 M)" % (n, ms, ms * 1e3 * (1 << 20) / n))
 print(os.path.basename(swmi.LIB_PATH), "|", " | ".join(res), "| checksum", int(out[: 1 << 20].sum().item()), flush=True)
 '''
-for rep in range(3):
-    for lib in sys.argv[1:3]:
+for rep in range(int(os.environ.get("AB_REPS", "3"))):
+    for lib in sys.argv[1:]:
         subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, SWMI_LIB=os.path.abspath(lib)), check=True)

@@ -151,8 +151,8 @@ def cost_of(op):
 
 def census(instrs, marker_op=None):
     """Split a kernel at its main loop and price both parts.  Main loop = the backward branch with the largest body, or --
-    when marker_op names an instruction only the hot loop issues (v_dot4_i32_i8 for the scorers) -- the innermost loop that
-    holds the most of them (a staging loop can be longer than a tight DP loop)."""
+    when marker_op names an instruction the hot loop issues (v_dot4_i32_i8 for the scorers) -- the innermost loop that
+    holds the most of them (a staging loop can be longer than a tight DP loop, and an enclosing loop holds more of everything)."""
     start = instrs[0]["addr"]
     loops = []
     for k, ins in enumerate(instrs):
@@ -165,9 +165,13 @@ def census(instrs, marker_op=None):
     if loops and marker_op:
         def marks(ab):
             return sum(1 for x in instrs[ab[0]:ab[1] + 1] if re.sub(r"_(e32|e64)$", "", x["op"]) == marker_op)
-        best = max(marks(ab) for ab in loops)
-        if best > 0:
-            main = min((ab for ab in loops if marks(ab) == best), key=lambda ab: ab[1] - ab[0])
+        # innermost: a loop that holds the marker but no other loop that holds it (the packed scorer's sweep sits inside a
+        # loop over the wavefront's sets of alignments, whose prologue uses the marker instruction too)
+        holders = [ab for ab in loops if marks(ab) > 0]
+        inner = [ab for ab in holders if not any(o != ab and ab[0] <= o[0] and o[1] <= ab[1] for o in holders)]
+        if inner:
+            best = max(marks(ab) for ab in inner)
+            main = min((ab for ab in inner if marks(ab) == best), key=lambda ab: ab[1] - ab[0])
 
     def tally(seq):
         t = {"instructions": len(seq), "valu": 0, "by_class": {}, "by_op": {}, "issue_cycles_ideal": 0.0,
