@@ -34,6 +34,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -298,18 +299,19 @@ def bench_banded(args, swmi, np, torch, local_rank, steps=None, warmup=None):
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     band_cells = sum(min(length, i + 63) - max(1, i - 64) + 1 for i in range(1, length + 1))
     value = P * steps / elapsed
-    # one wavefront per alignment; main loop = `length` iterations of two anti-diagonal steps (sw_banded_affine_kernel)
-    open_ge_ext = args.gap_open >= args.gap_extend
-    i16 = open_ge_ext and length * max(0, int(sm.max())) < 32768 and not os.environ.get("SWMI_BANDED_NO_I16")   # launch_banded_affine's rule
-    roof = issue_bound(r"^sw_banded_affine_kernel<%d,%d>$" % (1 if open_ge_ext else 0, 1 if i16 else 0), length, P, kernel_ms,
-                       marker=("v_dot4_i32_i8", 2))
+    # main loop = `length` iterations of two anti-diagonal steps; one wavefront per alignment (sw_banded_affine_kernel, int32
+    # cell) or per TWO alignments (sw_banded_affine_pk_kernel, 16-bit halves): the library says which it launched
+    kname, per_wave = swmi.banded_affine_kernel_for(length, sm, args.gap_open, args.gap_extend)
+    packed_cell = "_pk_" in kname
+    roof = issue_bound("^" + re.escape(kname) + "$", length, (P + per_wave - 1) // per_wave, kernel_ms,
+                       marker=("v_perm_b32", 2) if packed_cell else ("v_dot4_i32_i8", 2))
     # 12 algorithmic int ops per cell: 4 sub, 2+3 max, 1 add, 1 running max, 1 lookup (informational)
     roof.update({"kernel_ms": round(kernel_ms, 4), "traffic": None,
                  "achieved_algorithmic_tops": round(P * band_cells * 12 / (kernel_ms * 1e-3) / 1e12, 3),
                  "gcups_kernel": round(P * band_cells / (kernel_ms * 1e-3) / 1e9, 1)})
     line = {"metric": "alignments/sec (and GCUPS), banded affine extension", "value": round(value, 1), "unit": "alignments/s",
             "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16" if packed_cell else "int32", "data": "synthetic",
             "gcups": round(value * band_cells / 1e9, 1),
             "config": {"workload": "BASELINE.json configs[4] (extension, parity unpinned by the reference): %d pairs of %d-mers, "
                                    "128-diagonal band, sm 2/-3, gap open %d extend %d, inputs resident in HBM" % (
@@ -638,22 +640,44 @@ def single_gpu(args, swmi, np, torch, local_rank):
         # end-to-end through the host-buffer entry point (H2D + kernel + D2H; SURVEY 8d "reported separately"; never `value`):
         # the batch the reference's harness shape produces (1M pairs) and four times that, pageable host memory
         h1, h2 = swmi.generate_pairs_host(4 * P if P <= (1 << 20) else P, args.seed, 0)
-        hb = {"entry": "swmi_score_batch (pageable host memory, PCIe inclusive; granules: swmi_host_granules)"}
+        hb = {"entry": "swmi_score_batch (pageable host memory, PCIe inclusive; granules: swmi_host_granules_for)",
+              "stat": "median of 5 timed calls after one untimed (`ms`, `value`); `ms_min` = the fastest of the five"}
+
+        def timed_host(call, m, bytes_per_pair, entry_id, want):
+            call()
+            times = []
+            for _ in range(5):
+                t3 = time.perf_counter()
+                hs = call()
+                times.append(time.perf_counter() - t3)
+            times.sort()
+            med = times[2]
+            g = swmi.host_granules(int(m), entry_id)
+            return {"pairs": int(m), "ms": round(med * 1e3, 3), "ms_min": round(times[0] * 1e3, 3), "value": round(m / med, 1),
+                    "unit": "alignments/s", "h2d_gb_per_s": round(m * bytes_per_pair / med / 1e9, 1),
+                    "granules": g if len(g) <= 12 else "%d granules: %s ... %s" % (len(g), g[:3], g[-3:]),
+                    "matches_resident_scores": bool((hs[:len(want)] == want[:len(hs)]).all())}
         for label, m in (("pairs_1x", P), ("pairs_4x", h1.shape[0])):
             if label == "pairs_4x" and m == P:
                 continue
-            swmi.score_batch(h1[:m], h2[:m], sm, args.gap)
-            best = None
-            for _ in range(3):
-                t3 = time.perf_counter()
-                hs = swmi.score_batch(h1[:m], h2[:m], sm, args.gap)
-                dt3 = time.perf_counter() - t3
-                best = dt3 if best is None or dt3 < best else best
-            hb[label] = {"pairs": int(m), "ms": round(best * 1e3, 3), "value": round(m / best, 1), "unit": "alignments/s",
-                         "h2d_gb_per_s": round(m * 256 / best / 1e9, 1), "granules": swmi.host_granules(int(m)),
-                         "matches_resident_scores": bool((hs[:P] == head_scores).all())}
+            hb[label] = timed_host(lambda: swmi.score_batch(h1[:m], h2[:m], sm, args.gap), m, 256, swmi.ENTRY_PAIRS, head_scores)
+        # the same pairs through the reference's 2-bit wire format (source.cpp:1581; 64 B per pair over the link) and the
+        # one-vs-many entry (128 B per pair): each entry has its own granule schedule (swmi_api.cpp next_granule)
+        p1, p2 = swmi.pack(h1), swmi.pack(h2)
+        for label, m in (("pairs_1x", P), ("pairs_4x", h1.shape[0])):
+            if label == "pairs_4x" and m == P:
+                continue
+            hb.setdefault("packed", {"entry": "swmi_score_batch_packed (2-bit inputs, 64 B per pair over the link)"})[label] = timed_host(
+                lambda: swmi.score_batch_packed(p1[:m], p2[:m], sm, args.gap), m, 64, swmi.ENTRY_PACKED, head_scores)
+        ovm_want, _ = oracle_scores(np, h1[:4096], np.repeat(h2[:1], 4096, axis=0), sm, args.gap)
+        hb["one_vs_many"] = {"entry": "swmi_score_one_vs_many (128 B per pair over the link; checked against the CPU checker on 4096)",
+                             "pairs_1x": timed_host(lambda: swmi.score_one_vs_many(h1[:P], h2[0], sm, args.gap), P, 128,
+                                                    swmi.ENTRY_ONE_VS_MANY, ovm_want)}
+        del p1, p2
         hb.update({"ms": hb["pairs_1x"]["ms"], "value": hb["pairs_1x"]["value"], "unit": "alignments/s",
-                   "matches_resident_scores": all(v["matches_resident_scores"] for k, v in hb.items() if k.startswith("pairs_"))})
+                   "matches_resident_scores": all(v["matches_resident_scores"] for k, v in hb.items() if k.startswith("pairs_")) and
+                                              all(v["matches_resident_scores"] for k, v in hb["packed"].items() if k.startswith("pairs_")) and
+                                              hb["one_vs_many"]["pairs_1x"]["matches_resident_scores"]})
         line["host_buffer_path"] = hb
         del h1, h2
     if args.no_rows:
@@ -875,6 +899,14 @@ def multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank):
                        "parallelism": "batch-sharded x%d, one process per GPU, torch.distributed %s" % (world, args.backend),
                        "n1_note": "N = 1 runs configs[1] (1M pairs per step, no gather); legs.configs1_size_gather_every_step is that "
                                   "size on every GPU WITH the per-step gather"},
+            # what ONE GPU does at the SAME per-GPU batch: the no-gather leg of this very run, per GPU.  N = 1 of the default
+            # command times 1M pairs per step, where a step carries ~1.8 % of launch cost that a 64M-pair step amortises
+            # (profiles/r03_launch_ramp.txt), so value(N) / (N x value(1)) would read ~2 % high; value / (N x this) does not.
+            "n1_equivalent": {"value": round(legs["no_gather"]["value"] / world, 1), "unit": "alignments/s per GPU",
+                              "pairs_per_gpu": P,
+                              "how": "legs.no_gather.value / n_gpus (max over ranks of the wall time, same pairs per GPU, no gather); "
+                                     "a one-GPU run of this size, `bench.py --gpus 1 --pairs %d`, measured 1 002 M/s in round 3" % P,
+                              "scaling_efficiency_from_it": round(head["value"] / legs["no_gather"]["value"], 4)},
             "legs": legs, "roofline": roof, "checksum": checksum, "ranks_agree_on_gathered_scores": ranks_agree,
             "gpu_scores_checked": checked, "gpu_mismatches": mism,
             "checked_against": "%s on head / middle / tail samples of every one of the %d shards of the gathered vector" % (who, world),
@@ -891,6 +923,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    collective = world > 1 or args.force_dist
+    if collective:
+        # Runtime environment FIRST: the HSA / HIP runtimes read their variables when they initialise, which the first
+        # torch.cuda / swmi.init call below triggers (round 3 set these afterwards, where they did nothing; the driver's
+        # environment already carries HSA_ENABLE_IPC_MODE_LEGACY=0, this keeps a hand-started run equivalent)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the gather's kernels run beside a scoring kernel that always has thousands of workgroups queued: give their
+        # stream the dispatcher's preference so that they take the free wavefront slots as soon as they are ready
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -904,17 +951,7 @@ def main():
     local_rank %= n_dev                         # only differs from LOCAL_RANK in a gloo rehearsal on a smaller box
     torch.cuda.set_device(local_rank)
     swmi.init(local_rank)                       # raises if there is no gfx950 device: the bench never falls back
-    collective = world > 1 or args.force_dist
     if collective:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # the gather's kernels run beside a scoring kernel that always has thousands of workgroups queued: give their
-        # stream the dispatcher's preference so that they take the free wavefront slots as soon as they are ready
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        if world == 1:                          # rehearsal of the collective path on a one-GPU box (not a result)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL prints a version banner on STDOUT when the communicator comes up; the contract is ONE JSON line there, so
         # stdout points at stderr until the communicator exists
         sys.stdout.flush()

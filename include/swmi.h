@@ -105,11 +105,14 @@ SWMI_API int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq
  * as ONE call: pair k is the 128 bytes at seq1s + 128*k and seq2s + 128*k (the per-pair
  * layout of std::array<uint8_t,128>, concatenated).  Host buffers (pageable or pinned).  The PCIe link bounds this entry
  * (256 B per pair in, against ~1 ns of kernel time per pair), so the batch goes through the GPU in GRANULES on three device
- * buffer sets with a stream each: granule k's kernel runs while granule k+1 is being copied in, the granules taper (each is
- * three quarters of what is left, 1M pairs at most, 16K at least: a 1M-pair batch goes as 768K, 192K, 48K, 16K) so that
- * almost nothing is left to compute when the last copy ends, and the scores come back in ONE copy per 16M pairs after the
- * last kernel -- a copy into pageable memory blocks the caller until the stream reaches it, so copying scores back behind
- * every granule (round 2) serialised copy and kernel.  swmi_host_granules() reports the schedule.  The copies are issued
+ * buffer sets with a stream each: granule k's kernel runs while granule k+1 is being copied in, and the granules TAPER by the
+ * ratio of kernel time to copy time per pair, so that no kernel is still running when the next granule has landed and
+ * almost nothing is left to compute when the last copy ends: at 256 B per pair each granule is three quarters of what is
+ * left (1M pairs at most, 16K at least: a 1M-pair batch goes as 768K, 192K, 48K, 16K); the one-vs-many entry (128 B per
+ * pair) halves; the 2-bit packed entry (64 B per pair), whose copy and kernel take the same time, uses near-equal granules
+ * (DESIGN.md section 6).  The scores come back in ONE copy per 16M pairs after the last kernel -- a copy into pageable
+ * memory blocks the caller until the stream reaches it, so copying scores back behind
+ * every granule (round 2) serialised copy and kernel.  swmi_host_granules_for() reports the schedule.  The copies are issued
  * straight from the caller's memory (the HIP runtime stages pageable pages itself; an extra copy into library-owned pinned
  * memory measured slower); batches of up to 64 pairs go through a pinned, device-visible buffer
  * instead (no copy commands at all).  Thread-safe: calls on one context serialise.
@@ -121,6 +124,14 @@ SWMI_API int swmi_score_batch(const uint8_t *seq1s, const uint8_t *seq2s, size_t
 /* The granules a host batch of n pairs is cut into (the pipeline above), in order; returns how many there are and writes
  * the first `cap` sizes to granules (NULL to count).  Needs no device. */
 SWMI_API size_t swmi_host_granules(size_t n, size_t *granules, size_t cap);
+
+/* The same for any of the three host-batch entries: SWMI_ENTRY_PAIRS = swmi_score_batch (256 B per pair over the link;
+ * what swmi_host_granules reports), SWMI_ENTRY_PACKED = swmi_score_batch_packed (64 B), SWMI_ENTRY_ONE_VS_MANY =
+ * swmi_score_one_vs_many (128 B).  Returns 0 for an unknown entry.  Needs no device. */
+#define SWMI_ENTRY_PAIRS 0
+#define SWMI_ENTRY_PACKED 1
+#define SWMI_ENTRY_ONE_VS_MANY 2
+SWMI_API size_t swmi_host_granules_for(size_t n, int entry, size_t *granules, size_t cap);
 
 /* Same contract with all three buffers already resident in device memory (16-byte aligned
  * device pointers; `stream` is a hipStream_t, NULL meaning the HIP null stream as usual).
@@ -206,13 +217,19 @@ SWMI_API int swmi_sharded_time(swmi_sharded_batch *b, const int8_t score_matrix[
  * nothing in source.cpp; its semantics are defined by oracle/sw_oracle.c sw_oracle_banded_affine() and its
  * parity is NOT pinned by the reference.  n pairs of `len`-mers (64 <= len <= 1792, pair k at byte offset
  * len*k), local alignment restricted to the 128 diagonals -64 <= j - i <= 63, a gap of length k costs
- * gap_open + (k-1)*gap_extend (both in [0,127]).  One wavefront per alignment, see DESIGN.md section 9. */
+ * gap_open + (k-1)*gap_extend (both in [0,127]).  One wavefront per alignment -- or per TWO alignments that share every
+ * register as 16-bit halves (sw_banded_affine_pk_kernel, round 4) where len * max(s) + 2 max(0, -min s) + gap_open +
+ * gap_extend + 64 < 0x7C00; swmi_banded_affine_kernel_for() reports which -- see DESIGN.md section 9. */
 SWMI_API int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int len,
                                       const int8_t score_matrix[16], int gap_open, int gap_extend,
                                       int32_t *scores);
 SWMI_API int swmi_score_banded_affine_device(const void *d_seq1s, const void *d_seq2s, size_t n, int len,
                                              const int8_t score_matrix[16], int gap_open, int gap_extend,
                                              void *d_scores, void *stream);
+/* Which kernel instantiation a banded-affine launch with these parameters runs, e.g. "sw_banded_affine_pk_kernel<1>" or
+ * "sw_banded_affine_kernel<1,1>", and how many alignments one wavefront scores (2 / 1; NULL to skip).  Needs no device. */
+SWMI_API int swmi_banded_affine_kernel_for(int len, const int8_t score_matrix[16], int gap_open, int gap_extend, char *name,
+                                           size_t name_len, int *alignments_per_wavefront);
 
 /* ---- semi-global adaptive-band X-drop aligner -------------------------------------
  * Replaces SemiGlobal_AdaptiveBanded_XDrop_111_32_70 and its _simd / _simd_mark2..4 variants

@@ -996,6 +996,167 @@ sw_banded_affine_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__rest
     if (lane == 0) scores[pair] = best;
 }
 
+// ---- banded affine, TWO alignments per wavefront (round 4) ---------------------------------------------------------
+//
+// The 128 x 128 scorer's packing (section 5a of DESIGN.md) applied to the band: one register holds the SAME cell of two
+// alignments X (low half) and Y (high half), so the two share every instruction, and v_pk_maximum3_f16 -- a packed 3-way
+// INTEGER max on halves below 0x7C00 -- does per instruction what two v_max3_i32 did.  Same mapping as the int32 kernel above
+// (lane m owns diagonals 2m, 2m + 1 and alternates), same folding of the gap recurrences; what changes is the arithmetic:
+//   * every half is unsigned.  With B = max(0, -min s) the lookup yields s + B >= 0 and E, F travel as E + B, F + B:
+//         M = max3(H_diag + (s + B), E + B, F + B),   H = M -sat B                      (the zero floor of local alignment)
+//     A half that saturates at 0 stands for the true value -B or less; every non-positive E / F / hm is equivalent (H floors
+//     at 0 and E' = max(E, hm) - ext is monotone), so the clamps change nothing -- the argument of the int32 kernel, shifted by B.
+//   * lookup of both halves = ONE v_perm_b32: its eight source bytes are the score rows of X's and Y's ROW base (s + B, one
+//     byte per column base; staged in LDS per row), its selector comes from LDS per COLUMN (byte 0 <- X's column base, byte 2
+//     <- 4 + Y's, the other bytes constant zero).  Pads select nothing / hold zero rows: s + B = 0, the lowest score.
+//   * the two diagonal terms of an iteration (even and odd step) are ONE v_lshl_add_u64 over two aligned register pairs.
+//   * the value handed to a neighbour is floored by the max3's spare operand:  me = max3(E, hm, C)  with C >= the cost the
+//     receiver subtracts, so that subtraction is a plain 32-bit one (no half borrows) -- v_sub_u32, and for the value that
+//     crosses lanes v_sub_u32_dpp with the lane shift riding on it (VOP3P has no DPP form; a v_pk_sub_u16 clamp would need a
+//     v_mov_b32_dpp in front).  The band's edge lanes, whose DPP source does not exist and reads 0, subtract 0.
+//       open >= ext:  hm = M -sat (open - ext);  me = max3(E, hm, ext);             E' = me - ext
+//       open <  ext:  em = E -sat (ext - open);  me = max3(em, M, max(B, open));    E' = me - open     (M stands in for H + B:
+//                     the floor max(B, open) >= B repairs M < B, and it is <= B + open, i.e. E' <= 0 in true terms)
+//   Per cell and PAIR of alignments: perm, 1/2 paired add, max3, 2 sat-sub, 2 max3, 2 sub, 1/2 max3 (running best) = 9
+//   instructions (10 for open < ext) = 4.5 per alignment-cell against the int32 kernel's 8.25.
+// Domain (decided on the host, launch_banded_affine): len * max(s, 0) + 2 B + open + ext + 64 < 0x7C00; else the int32 kernel.
+__device__ __forceinline__ unsigned ba_pk_max3(unsigned a, unsigned b, unsigned c)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)), __builtin_bit_cast(h2, c));
+    return __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ unsigned ba_pk_sub_sat(unsigned v, unsigned d)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, v), __builtin_bit_cast(us2, d)));
+}
+
+struct BandedPkParams {
+    uint32_t rows[4];          // rows[a]: s(a, b) + B in byte b
+    uint32_t bias2;            // B in both halves
+    uint32_t fold2;            // |open - ext| in both halves
+    uint32_t cost2;            // what a handed-over value loses on arrival (ext resp. open) in both halves
+    uint32_t floor2;           // the max3's spare operand C in both halves
+};
+
+template <bool kOpenGeExt>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+sw_banded_affine_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
+                           uint32_t n, int len, BandedPkParams prm)
+{
+    // per wave: row entries [len + 72] x 2 dwords (X's, Y's score row) then column selectors [len + 72], 32 pads in front
+    extern __shared__ uint32_t lds_dyn[];
+    __shared__ uint32_t lds_rows[kWavesPerBlock][4];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t wave_id = blockIdx.x * kWavesPerBlock + wv;
+    const uint32_t pair_x = 2 * wave_id;
+    if (pair_x >= n) return;                    // wave-uniform; only wave-level synchronisation below
+    const uint32_t pair_y = pair_x + 1 < n ? pair_x + 1 : pair_x;          // an odd batch's last wavefront scores its pair twice
+    const int stride = len + 72;
+    uint2 *arow = reinterpret_cast<uint2 *>(lds_dyn + (size_t)wv * 3 * stride);
+    uint32_t *bsel = lds_dyn + (size_t)wv * 3 * stride + 2 * stride;
+
+    keep_f16_denormals();
+    if (lane < 4) lds_rows[wv][lane] = prm.rows[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t *x1 = seq1s + (size_t)pair_x * (size_t)len, *x2 = seq2s + (size_t)pair_x * (size_t)len;
+    const uint8_t *y1 = seq1s + (size_t)pair_y * (size_t)len, *y2 = seq2s + (size_t)pair_y * (size_t)len;
+    for (int kp = lane; kp < stride; kp += 64) {                // entry kp holds position kp - 32 of the sequences
+        const int k = kp - 32;
+        const bool in = (unsigned)k < (unsigned)len;
+        const uint32_t ax = in ? (x1[k] & 3u) : 0u, ay = in ? (y1[k] & 3u) : 0u;
+        const uint32_t bx = in ? (x2[k] & 3u) : 0u, by = in ? (y2[k] & 3u) : 0u;
+        arow[kp] = in ? make_uint2(lds_rows[wv][ax], lds_rows[wv][ay]) : make_uint2(0u, 0u);      // pad rows: s + B = 0
+        bsel[kp] = in ? (0x0C000C00u | bx | ((4u + by) << 16)) : 0x0C0C0C0Cu;                      // pad columns select zero
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // iteration u: lane m at row i = 33 - m + u, columns j = u + m - 31 (even step) and j + 1 (odd step), 1-based
+    const uint2 *pa = arow + (64 - lane);       // pa[u] = score rows of row i
+    const uint32_t *pb = bsel + lane;           // pb[u] = selector of column j, pb[u + 1] of column j + 1
+    uint2 a_cur = pa[0];
+    uint32_t b_cur = pb[0];
+    const unsigned bias2 = prm.bias2, fold2 = prm.fold2, cost2 = prm.cost2, floor2 = prm.floor2;
+    // the subtrahend of the lane-crossing subtractions sits in a VGPR (gfx9 DPP takes no SGPR operand) and is 0 in the lane
+    // whose source lane does not exist (that lane's DPP read yields 0)
+    const unsigned cost_left = lane == 0 ? 0u : cost2, cost_up = lane == 63 ? 0u : cost2;
+    unsigned best = bias2;
+    unsigned h0 = 0, h1 = 0;                    // H of the last cell on diagonals 2m / 2m + 1 (X low, Y high)
+    unsigned me0 = floor2, mf0 = floor2, me1 = floor2, mf1 = floor2;
+    auto hand_over = [&](unsigned m, unsigned e, unsigned f, unsigned &me, unsigned &mf) {
+        if constexpr (kOpenGeExt) {
+            const unsigned hm = ba_pk_sub_sat(m, fold2);
+            me = ba_pk_max3(e, hm, floor2);
+            mf = ba_pk_max3(f, hm, floor2);
+        } else {
+            const unsigned em = ba_pk_sub_sat(e, fold2), fm = ba_pk_sub_sat(f, fold2);
+            me = ba_pk_max3(em, m, floor2);
+            mf = ba_pk_max3(fm, m, floor2);
+        }
+    };
+    auto pair_of_steps = [&](uint32_t b_next) {
+        // both diagonal terms at once: (h0, h1) + (lookup of (i, j), lookup of (i, j + 1))
+        const unsigned p0 = __builtin_amdgcn_perm(a_cur.y, a_cur.x, b_cur), p1 = __builtin_amdgcn_perm(a_cur.y, a_cur.x, b_next);
+        // (written as a C addition hipcc splits it again -- a 64-bit add of (h0, 0) and a v_add_u32 for h1 -- so the instruction
+        // is named; no half ever carries: every sum stays below 0x7C00)
+        unsigned long long t;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"((unsigned long long)h0 | ((unsigned long long)h1 << 32)),
+                                                        "v"((unsigned long long)p0 | ((unsigned long long)p1 << 32)));
+        const unsigned t0 = (unsigned)t, t1 = (unsigned)(t >> 32);
+        unsigned m0, m1;
+        {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
+            const unsigned e = (unsigned)__builtin_amdgcn_update_dpp(0, (int)me1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - cost_left;
+            const unsigned f = mf1 - cost2;
+            m0 = ba_pk_max3(t0, e, f);
+            h0 = ba_pk_sub_sat(m0, bias2);
+            hand_over(m0, e, f, me0, mf0);
+        }
+        {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
+            const unsigned e = me0 - cost2;
+            const unsigned f = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mf0, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) - cost_up;
+            m1 = ba_pk_max3(t1, e, f);
+            h1 = ba_pk_sub_sat(m1, bias2);
+            hand_over(m1, e, f, me1, mf1);
+        }
+        best = ba_pk_max3(best, m0, m1);
+        b_cur = b_next;
+    };
+    int u = 0;
+#pragma unroll 1
+    for (; u + 4 <= len; u += 4) {              // four iterations per trip: LDS offsets become immediates
+        const uint32_t b1 = pb[u + 1], b2 = pb[u + 2], b3 = pb[u + 3], b4 = pb[u + 4];
+        const uint2 a1 = pa[u + 1], a2 = pa[u + 2], a3 = pa[u + 3], a4 = pa[u + 4];
+        pair_of_steps(b1); a_cur = a1;
+        pair_of_steps(b2); a_cur = a2;
+        pair_of_steps(b3); a_cur = a3;
+        pair_of_steps(b4); a_cur = a4;
+    }
+    for (; u < len; ++u) {
+        const uint32_t b_next = pb[u + 1];
+        const uint2 a_next = pa[u + 1];
+        pair_of_steps(b_next);
+        a_cur = a_next;
+    }
+    int bx = (int)(best & 0xFFFFu), by = (int)(best >> 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o);
+        bx = bx > ox ? bx : ox;
+        by = by > oy ? by : oy;
+    }
+    if (lane == 0) {
+        const int b = (int)(bias2 & 0xFFFFu);
+        scores[pair_x] = bx - b;
+        if (pair_x + 1 < n) scores[pair_x + 1] = by - b;
+    }
+}
+
 // ---- synthetic input generator (specification in include/swmi.h) -----------------------------------
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
@@ -1116,22 +1277,63 @@ hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_se
     return launch_mode<2>(cfg, d_seq1s, d_seq2, d_scores, n_seq1, rows, gap, stream);
 }
 
-hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
-                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream, bool allow_i16)
+// Which kernel a banded-affine launch runs: 2 = packed (two alignments per wavefront), 1 = int32 cell with 16-bit maxes,
+// 0 = int32 cell.  The packed kernel needs every half to stay a finite half-precision pattern.
+int banded_affine_kernel_choice(int len, const SmRows &rows, int gap_open, int gap_ext, bool allow_i16, bool allow_pk)
 {
-    if (n == 0) return hipSuccess;
-    const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 72) * sizeof(uint32_t);
-    // 16-bit maxes are exact while no H can reach 2^15: H <= len * (largest score, at least 0)
-    int top = 0;
+    int top = 0, low = 0;
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 4; ++b) {
             const int v = (int)(int8_t)(rows.r[a] >> (8 * b));
             top = v > top ? v : top;
+            low = v < low ? v : low;
         }
-    const bool i16 = (long long)len * top < 32768 && allow_i16;
-    const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+    const long long bias = -low;
+    if (allow_pk && (long long)len * top + 2 * bias + gap_open + gap_ext + 64 < 0x7C00) return 2;
+    // 16-bit maxes are exact while no H can reach 2^15: H <= len * (largest score, at least 0)
+    return (long long)len * top < 32768 && allow_i16 ? 1 : 0;
+}
+
+hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
+                                const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream, bool allow_i16, bool allow_pk)
+{
+    if (n == 0) return hipSuccess;
+    const int choice = banded_affine_kernel_choice(len, rows, gap_open, gap_ext, allow_i16, allow_pk);
+    const dim3 block(64 * kWavesPerBlock);
+    if (choice == 2) {
+        const size_t waves = (n + 1) / 2, blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+        const size_t lds = (size_t)kWavesPerBlock * 3 * (size_t)(len + 72) * sizeof(uint32_t);
+        int low = 0;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const int v = (int)(int8_t)(rows.r[a] >> (8 * b));
+                low = v < low ? v : low;
+            }
+        const unsigned bias = (unsigned)-low;
+        BandedPkParams prm;
+        for (int a = 0; a < 4; ++a) {
+            uint32_t r = 0;
+            for (int b = 0; b < 4; ++b) r |= (uint32_t)((int)(int8_t)(rows.r[a] >> (8 * b)) + (int)bias) << (8 * b);
+            prm.rows[a] = r;
+        }
+        const bool oge = gap_open >= gap_ext;
+        const unsigned fold = (unsigned)(oge ? gap_open - gap_ext : gap_ext - gap_open), cost = (unsigned)(oge ? gap_ext : gap_open);
+        const unsigned floor_c = oge ? cost : (bias > cost ? bias : cost);
+        prm.bias2 = bias * 0x10001u;
+        prm.fold2 = fold * 0x10001u;
+        prm.cost2 = cost * 0x10001u;
+        prm.floor2 = floor_c * 0x10001u;
+        const dim3 grid((unsigned)blocks);
+        if (oge) hipLaunchKernelGGL((sw_banded_affine_pk_kernel<true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, prm);
+        else     hipLaunchKernelGGL((sw_banded_affine_pk_kernel<false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, prm);
+        return hipGetLastError();
+    }
+    const size_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)kWavesPerBlock * 2 * (size_t)(len + 72) * sizeof(uint32_t);
+    const bool i16 = choice == 1;
+    const dim3 grid((unsigned)blocks);
     if (gap_open >= gap_ext) {
         if (i16) hipLaunchKernelGGL((sw_banded_affine_kernel<true, true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);
         else     hipLaunchKernelGGL((sw_banded_affine_kernel<true, false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, rows, gap_open, gap_ext);

@@ -69,9 +69,15 @@ void read_knobs()
     };
     k.host_granule = (size_t)num("SWMI_HOST_GRANULE", 1024, (long long)kChunkPairs, 0);
     k.host_serial = num("SWMI_HOST_SERIAL", 0, 1, 0) != 0;
+    k.host_taper_pct = (unsigned)num("SWMI_HOST_TAPER", 1, 99, 0);
+    k.host_min_granule = (size_t)num("SWMI_HOST_MIN_GRANULE", 1024, (long long)kChunkPairs, 0);
+    k.host_threads = (int)num("SWMI_HOST_THREADS", 1, kHostThreads, 0);
+    k.host_slots = (int)num("SWMI_HOST_SLOTS", 2, kSlots / kHostThreads, 0);
+    k.score_group = (size_t)num("SWMI_TEST_SCORE_GROUP", 4096, (long long)kScoreGroup, (long long)kScoreGroup);
     k.extra_lds = (unsigned)num("SWMI_EXTRA_LDS", 0, 160 * 1024, 0);
     k.lanes = (int)num("SWMI_LANES", 0, 64, 0);
     k.banded_no_i16 = getenv("SWMI_BANDED_NO_I16") != nullptr;
+    k.banded_no_pk = getenv("SWMI_BANDED_NO_PK") != nullptr;
     k.sg_sweep = (int)num("SWMI_SG_SWEEP", 1, 44, -1);
     const char *gb = getenv("SWMI_GATHER_BACKEND");
     k.gather_p2p = gb && strcmp(gb, "p2p") == 0;
@@ -197,17 +203,23 @@ LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *
 }
 
 namespace {
-int ensure_slot(Slot &s, size_t pairs)
+// bytes: what each of the slot's two input buffers must hold; scores: entries of the slot's own score buffer (0 = none)
+int ensure_slot(Slot &s, size_t bytes, size_t scores)
 {
-    if (s.capacity >= pairs) return SWMI_OK;
-    if (s.d_seq1) { (void)hipFree(s.d_seq1); s.d_seq1 = nullptr; }
-    if (s.d_seq2) { (void)hipFree(s.d_seq2); s.d_seq2 = nullptr; }
-    if (s.d_scores) { (void)hipFree(s.d_scores); s.d_scores = nullptr; }
-    s.capacity = 0;
-    SWMI_HIP_TRY(hipMalloc(&s.d_seq1, pairs * kSeq));
-    SWMI_HIP_TRY(hipMalloc(&s.d_seq2, pairs * kSeq));
-    SWMI_HIP_TRY(hipMalloc(&s.d_scores, pairs * sizeof(int32_t)));
-    s.capacity = pairs;
+    if (s.capacity < bytes) {
+        if (s.d_seq1) { (void)hipFree(s.d_seq1); s.d_seq1 = nullptr; }
+        if (s.d_seq2) { (void)hipFree(s.d_seq2); s.d_seq2 = nullptr; }
+        s.capacity = 0;
+        SWMI_HIP_TRY(hipMalloc(&s.d_seq1, bytes));
+        SWMI_HIP_TRY(hipMalloc(&s.d_seq2, bytes));
+        s.capacity = bytes;
+    }
+    if (s.score_capacity < scores) {
+        if (s.d_scores) { (void)hipFree(s.d_scores); s.d_scores = nullptr; }
+        s.score_capacity = 0;
+        SWMI_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_scores), scores * sizeof(int32_t)));
+        s.score_capacity = scores;
+    }
     return SWMI_OK;
 }
 
@@ -228,20 +240,42 @@ int launch_device(Context &ctx, const void *d1, const void *d2, size_t n, const 
     return SWMI_OK;
 }
 
-// Pipeline granules of a host batch.  The link, not the kernel, bounds this path (256 B per pair over PCIe against
-// ~1.1 ns of kernel time per pair), so the schedule is built to keep the link busy and to leave as little as possible
-// behind the last copy: granules TAPER -- each is three quarters of what is left, at most kChunkPairs, and whatever is left
-// below kMinGranule goes as one -- so the kernel that runs exposed at the very end covers 16 K pairs (~30 us), while the
-// number of copy commands stays small (a 1M-pair batch: 768 K, 192 K, 48 K, 16 K).  A kernel is ~4x faster than the copy of
-// its own granule, so granule k's kernel is always done before granule k + 1's (smaller) copy is.
-size_t next_granule(size_t remaining)
+// Pipeline granules of a host batch.  Copies run back to back on the link (c seconds per pair), kernels back to back on the
+// GPU (k seconds per pair); granule i's kernel can start when its copy has landed, so the batch ends at n c + (last
+// granule) k PROVIDED no kernel is still running when the next granule's copy lands: g[i+1] c >= g[i] k.  The schedule
+// therefore TAPERS geometrically with the ratio f = k / c (plus a margin): each granule is (1 - f) of what is left, at most
+// kChunkPairs, and whatever is left below the smallest granule goes as one.  k is ~1.07 ns per pair for every entry, c is
+// the entry's bytes per pair over the ~53.6 GB/s a PCIe Gen5 x16 link delivers from pageable memory, so f = 59 / bytes
+// per pair; with the margin, 64 / bytes:
+//   pairs        256 B  f = 1/4   1M pairs go as 768 K, 192 K, 48 K, 16 K (the kernel is ~4x faster than its granule's copy)
+//   one-vs-many  128 B  f = 1/2   512 K, 256 K, 128 K, 64 K, 32 K, 16 K, 16 K
+//   2-bit packed  64 B  f -> 1    copy and kernel take the same time: (near-)equal granules, the end exposed is one
+//                                  granule's kernel.  Round 3 ran this entry on the 256-byte taper: its 768 K-pair kernel
+//                                  (0.8 ms) then ran after a 0.9 ms copy with only 0.3 ms of copies left to hide under.
+// SWMI_HOST_TAPER / SWMI_HOST_MIN_GRANULE / SWMI_HOST_GRANULE override f (percent), the smallest and a fixed granule
+// (tools/host_pipeline_experiment.py).
+size_t host_entry_bytes(int entry)
 {
-    const size_t fixed = knobs().host_granule;
-    if (fixed) return remaining < fixed ? remaining : fixed;
-    if (remaining <= kMinGranule) return remaining;
-    size_t g = (remaining - remaining / 4) & ~size_t(4095);
+    return entry == kEntryPacked ? 2 * SWMI_PACKED_LEN : entry == kEntryOneVsMany ? kSeq : 2 * kSeq;
+}
+
+size_t next_granule(size_t remaining, size_t bytes_per_pair)
+{
+    const Knobs &kn = knobs();
+    if (kn.host_granule) return remaining < kn.host_granule ? remaining : kn.host_granule;
+    if (bytes_per_pair * 15 <= 1024 && !kn.host_taper_pct) {       // f would exceed 15/16: copy and kernel are level
+        // equal granules, small ones: the end exposed is one granule's kernel, and with two issuing threads (score_host_batch)
+        // the fixed cost of a copy command hides under the other thread's copy; a long batch starts on larger ones
+        const size_t g = kn.host_min_granule ? kn.host_min_granule : remaining > 32 * kBalancedGranule ? 2 * kBalancedGranule : kBalancedGranule;
+        return remaining < g ? remaining : g;
+    }
+    const size_t smallest = kn.host_min_granule ? kn.host_min_granule : kMinGranule;
+    if (remaining <= smallest) return remaining;
+    size_t f1024 = kn.host_taper_pct ? size_t(kn.host_taper_pct) * 1024 / 100 : 65536 / bytes_per_pair;
+    if (f1024 > kMaxTaper1024) f1024 = kMaxTaper1024;
+    size_t g = (remaining - remaining * f1024 / 1024) & ~size_t(4095);
     if (g > kChunkPairs) g = kChunkPairs;
-    if (g < kMinGranule) g = kMinGranule;
+    if (g < smallest) g = smallest;
     return g;
 }
 
@@ -258,71 +292,142 @@ int ensure_scores_all(Context &ctx, size_t pairs)
 }  // namespace
 
 // Host-resident batch (the body of swmi_score_batch and its relatives).  kSlots input buffer sets, a stream each;
-// granule k: H2D of its two arrays, then its kernel, on stream k % kSlots, writing into ONE device score vector for the
+// granule k: H2D of its two arrays, then its kernel, on one slot's stream, writing into ONE device score vector for the
 // whole group of granules.  Nothing is copied back until every granule of the group has been issued: a copy into pageable
 // memory blocks the calling thread until the stream reaches it, and round 2's pipeline -- D2H behind every granule --
 // therefore never had granule k + 1's H2D in flight while granule k's kernel ran (profiles/r02_host_staging_experiment.txt:
-// 4 x (4.9 + 1.5) ms for 4M pairs).  Now the host is only ever blocked inside an H2D copy (pageable memory) or not at all
-// (pinned), granule k's kernel runs under granule k + 1's copy, and one D2H per group (up to kScoreGroup pairs, 64 MiB of
-// scores) follows the group's last kernel.
+// 4 x (4.9 + 1.5) ms for 4M pairs).  One D2H per group (up to kScoreGroup pairs, 64 MiB of scores) follows the group's last
+// kernel.
+// TWO host threads issue the granules, even ones on the calling thread, odd ones on the context's persistent helper
+// (round 4): a copy command from pageable memory costs the issuing thread ~20 us of set-up and tear-down around its DMA
+// (the runtime pins and unpins the pages) during which the link idles -- 8 commands per 1M packed pairs, 0.2 ms of 1.75 --
+// and with two threads one command's DMA runs while the other thread prepares the next.  Each thread rotates over its own
+// two slots, so buffer reuse stays ordered by the slot's stream.
+namespace {
+struct Granule { size_t off, m; };                   // inside its group
+
+// issue granules first, first + step, ... of `list` (one issuing thread's share); slots[] = this thread's buffer sets
+hipError_t issue_granules(Context &ctx, const std::vector<Granule> &list, size_t first, size_t step, Slot *const *slots, int n_slots,
+                          const uint8_t *s1, const uint8_t *s2, size_t group, size_t in_stride, const int8_t *sm, int gap,
+                          int32_t *out, bool packed, bool one_vs_many, bool serial, bool *slot_used)
+{
+    hipError_t e = hipSuccess;
+    size_t j = 0;
+    for (size_t i = first; i < list.size() && e == hipSuccess; i += step, ++j) {
+        const size_t off = list[i].off, m = list[i].m, at = group + off;
+        const int which = int(j % size_t(n_slots));
+        Slot &s = *slots[which];
+        SmRows rows;
+        const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, m);      // a small tail granule runs more lanes per alignment
+        e = hipMemcpyAsync(s.d_seq1, s1 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess && !one_vs_many)
+            e = hipMemcpyAsync(s.d_seq2, s2 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess)
+            e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, s.stream)
+                            : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, packed, s.stream);
+        if (e == hipSuccess && serial)
+            e = hipMemcpyAsync(out + at, ctx.d_scores_all + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+        slot_used[which] = true;
+    }
+    return e;
+}
+}  // namespace
+
 int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
                      bool packed, bool one_vs_many)
 {
     std::lock_guard<std::mutex> lock(ctx.mu);
     const size_t in_stride = packed ? SWMI_PACKED_LEN : kSeq;
+    const size_t per_pair = host_entry_bytes(packed ? kEntryPacked : one_vs_many ? kEntryOneVsMany : kEntryPairs);
     const bool serial = knobs().host_serial;             // round 2's order of issue, for the A/B
-    const size_t largest = next_granule(n);
-    int used_slots = 0;
-    {
-        size_t rem = n;
-        while (rem && used_slots < kSlots) { rem -= next_granule(rem); ++used_slots; }
-    }
+    const size_t score_group = knobs().score_group;
+    const size_t first_group = n < score_group ? n : score_group;
+    const size_t largest = next_granule(first_group, per_pair);       // granules only shrink within a group, and no group is larger
+    size_t first_count = 0;
+    for (size_t rem = first_group; rem; ++first_count) rem -= next_granule(rem, per_pair);
+    // issuing threads: two where copy and kernel are level (the 2-bit packed entry) and there is more than one granule; where
+    // the link alone is the bound (256 / 128 bytes per pair) a second thread only makes the two threads' copies and kernels
+    // compete (measured: profiles/r04_host_pipeline_experiment.txt)
+    const bool balanced = per_pair * 15 <= 1024;
+    const int want_threads = knobs().host_threads ? knobs().host_threads : balanced ? 2 : 1;
+    const int threads = (serial || want_threads < 2 || first_count < 2) ? 1 : 2;
+    // buffer sets: three per issuing thread (a thread's copies may run two granules ahead of its kernels)
+    const int per_thread = knobs().host_slots ? knobs().host_slots : 3;
+    const int used_slots = threads == 2 ? 2 * per_thread : n > score_group || first_count > size_t(per_thread) ? per_thread : int(first_count);
     for (int k = 0; k < used_slots; ++k) {
-        const int rc = ensure_slot(ctx.slots[k], largest);
+        const int rc = ensure_slot(ctx.slots[k], largest * in_stride, 0);
         if (rc != SWMI_OK) return rc;
     }
     {
-        const int rc = ensure_scores_all(ctx, n < kScoreGroup ? n : kScoreGroup);
+        const int rc = ensure_scores_all(ctx, first_group);
         if (rc != SWMI_OK) return rc;
     }
+    if (threads == 2 && !ctx.copier) ctx.copier.reset(new Worker);
     hipError_t e = hipSuccess;
     if (one_vs_many)   // the single seq2 goes to the head of the seq2 buffer of every slot in use
         for (int k = 0; k < used_slots && e == hipSuccess; ++k)
             e = hipMemcpyAsync(ctx.slots[k].d_seq2, s2, kSeq, hipMemcpyHostToDevice, ctx.slots[k].stream);
-    size_t idx = 0;
-    for (size_t group = 0; group < n && e == hipSuccess; group += kScoreGroup) {
-        const size_t group_n = n - group < kScoreGroup ? n - group : kScoreGroup;
-        bool slot_used[kSlots] = {};
-        Slot *last_slot = nullptr;
-        for (size_t off = 0; off < group_n && e == hipSuccess; ++idx) {
-            const size_t m = next_granule(group_n - off), at = group + off;
-            const int which = int(idx % kSlots);
-            Slot &s = ctx.slots[which];
-            SmRows rows;
-            const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, m);      // a small tail granule runs more lanes per alignment
-            e = hipMemcpyAsync(s.d_seq1, s1 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
-            if (e == hipSuccess && !one_vs_many)
-                e = hipMemcpyAsync(s.d_seq2, s2 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
-            if (e == hipSuccess)
-                e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, s.stream)
-                                : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, packed, s.stream);
-            if (e == hipSuccess && serial)
-                e = hipMemcpyAsync(out + at, ctx.d_scores_all + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
-            slot_used[which] = true;
-            last_slot = &s;
+    // thread t's slots: t, t + threads, ... (one thread: all of them in turn)
+    Slot *mine[kSlots], *theirs[kSlots];
+    int n_mine = 0, n_theirs = 0;
+    for (int k = 0; k < used_slots; ++k) {
+        if (threads == 1 || k % 2 == 0) mine[n_mine++] = &ctx.slots[k];
+        else                            theirs[n_theirs++] = &ctx.slots[k];
+    }
+    std::vector<Granule> list;
+    for (size_t group = 0; group < n && e == hipSuccess; group += score_group) {
+        const size_t group_n = n - group < score_group ? n - group : score_group;
+        list.clear();
+        for (size_t off = 0; off < group_n;) {
+            const size_t m = next_granule(group_n - off, per_pair);
+            list.push_back(Granule{off, m});
             off += m;
         }
-        if (e != hipSuccess || serial || !last_slot) continue;
-        // the group's scores: one copy on the last granule's stream, behind every other slot's last kernel
-        for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
-            if (!slot_used[k] || &ctx.slots[k] == last_slot) continue;
-            e = hipEventRecord(ctx.slot_done[k], ctx.slots[k].stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(last_slot->stream, ctx.slot_done[k], 0);
+        bool used_mine[kSlots] = {}, used_theirs[kSlots] = {};
+        hipError_t e2 = hipSuccess;
+        if (threads == 2 && list.size() > 1) {
+            const int device = ctx.device;
+            ctx.copier->submit([&, device] {
+                e2 = hipSetDevice(device);                  // per host thread, like every HIP "current device"
+                if (e2 == hipSuccess)
+                    e2 = issue_granules(ctx, list, 1, 2, theirs, n_theirs, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many,
+                                        serial, used_theirs);
+            });
+            e = issue_granules(ctx, list, 0, 2, mine, n_mine, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many, serial, used_mine);
+            ctx.copier->wait();                             // (it has ISSUED its share; the streams may still be busy)
+            if (e == hipSuccess) e = e2;
+        } else {
+            e = issue_granules(ctx, list, 0, 1, mine, n_mine, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many, serial, used_mine);
         }
+        if (e != hipSuccess) break;
+        // the slot that took the group's LAST granule carries the score copy
+        const size_t last = list.size() - 1;
+        const bool last_is_mine = threads == 1 || list.size() == 1 || last % 2 == 0;
+        const size_t last_j = threads == 1 || list.size() == 1 ? last : last / 2;
+        Slot *last_slot = last_is_mine ? mine[last_j % size_t(n_mine)] : theirs[last_j % size_t(n_theirs)];
+        const bool more = group + group_n < n;
+        if (serial) {
+            // every granule copied its own scores back on its own stream; the next group's kernels overwrite d_scores_all, so
+            // every stream that still holds such a copy has to drain first (a copy into pinned memory does not block the caller)
+            for (int k = 0; k < n_mine && more && e == hipSuccess; ++k)
+                if (used_mine[k]) e = hipStreamSynchronize(mine[k]->stream);
+            continue;
+        }
+        // the group's scores: one copy on the last granule's stream, behind every other slot's last kernel
+        auto join = [&](Slot *s) {
+            if (s == last_slot || e != hipSuccess) return;
+            hipEvent_t ev = ctx.slot_done[s - ctx.slots];
+            e = hipEventRecord(ev, s->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(last_slot->stream, ev, 0);
+        };
+        for (int k = 0; k < n_mine; ++k)
+            if (used_mine[k]) join(mine[k]);
+        for (int k = 0; k < n_theirs; ++k)
+            if (used_theirs[k]) join(theirs[k]);
         if (e == hipSuccess)
             e = hipMemcpyAsync(out + group, ctx.d_scores_all, group_n * sizeof(int32_t), hipMemcpyDeviceToHost, last_slot->stream);
-        // the next group overwrites d_scores_all: drain this one first (only batches above kScoreGroup pairs get here twice)
-        if (e == hipSuccess && group + group_n < n) e = hipStreamSynchronize(last_slot->stream);
+        // the next group overwrites d_scores_all: drain this one first (only batches above the score group get here twice)
+        if (e == hipSuccess && more) e = hipStreamSynchronize(last_slot->stream);
     }
     for (int k = 0; k < kSlots; ++k)
         if (ctx.slots[k].stream) {
@@ -377,6 +482,7 @@ int queue_ship(swmi_queue *q, size_t upto)
 
 void destroy_context(Context &c)
 {
+    c.copier.reset();                   // joins the helper thread (idle: host batches hold c.mu while it works)
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     for (auto &s : c.slots) {
@@ -453,7 +559,9 @@ int init_list(const int *devices, int n)
     (void)hipSetDevice(devices[0]);
     g_ctxs = std::move(fresh);
     if (knobs().lanes && swmi::schedule_supported(knobs().lanes)) g_schedule.store(uint64_t(knobs().lanes));
-    if (swmi_semiglobal_set_mapping(knobs().sg_sweep) != SWMI_OK) (void)swmi_semiglobal_set_mapping(-1);   // (a value it rejects: automatic)
+    // like SWMI_LANES above: the environment gives an initial value only when it is set; a mapping the program chose
+    // through swmi_semiglobal_set_mapping survives a shutdown / re-init
+    if (knobs().sg_sweep >= 0 && swmi_semiglobal_set_mapping(knobs().sg_sweep) != SWMI_OK) (void)swmi_semiglobal_set_mapping(-1);
     return SWMI_OK;
 }
 
@@ -747,8 +855,23 @@ static int banded_device(Context &ctx, const void *d_seq1s, const void *d_seq2s,
         HIP_TRY(swmi::launch_banded_affine(static_cast<const uint8_t *>(d_seq1s) + off * size_t(len),
                                            static_cast<const uint8_t *>(d_seq2s) + off * size_t(len),
                                            static_cast<int32_t *>(d_scores) + off, m, len, rows, gap_open, gap_extend, stream,
-                                           !knobs().banded_no_i16));
+                                           !knobs().banded_no_i16, !knobs().banded_no_pk));
     }
+    return SWMI_OK;
+}
+
+int swmi_banded_affine_kernel_for(int len, const int8_t score_matrix[16], int gap_open, int gap_extend, char *name, size_t name_len,
+                                  int *alignments_per_wavefront)
+{
+    const int rc = check_banded(score_matrix, len, gap_open, gap_extend);
+    if (rc != SWMI_OK) return rc;
+    if (!name || name_len == 0) return fail(SWMI_ERR_INVALID_ARGUMENT, "no name buffer");
+    const int choice = swmi::banded_affine_kernel_choice(len, pack_rows(score_matrix, 0), gap_open, gap_extend, !knobs().banded_no_i16,
+                                                         !knobs().banded_no_pk);
+    const int oge = gap_open >= gap_extend ? 1 : 0;
+    if (choice == 2) snprintf(name, name_len, "sw_banded_affine_pk_kernel<%d>", oge);
+    else             snprintf(name, name_len, "sw_banded_affine_kernel<%d,%d>", oge, choice);
+    if (alignments_per_wavefront) *alignments_per_wavefront = choice == 2 ? 2 : 1;
     return SWMI_OK;
 }
 
@@ -774,12 +897,11 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
     Context *ctx = current();
     if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
-    // the slot buffers are sized in 128-byte pairs: a len-mer pair occupies ceil(len / 128) of them
-    const size_t per = (size_t(len) + kSeq - 1) / kSeq;
-    const size_t chunk_cap = kChunkPairs / per;
+    // chunks of at most 128 MiB per input array, as in the 128 x 128 pipeline
+    const size_t chunk_cap = kChunkPairs * kSeq / size_t(len);
     const size_t chunk = n < chunk_cap ? n : chunk_cap;
     for (int k = 0; k < kSlots && size_t(k) * chunk < n; ++k) {
-        rc = ensure_slot(ctx->slots[k], chunk * per);
+        rc = ensure_slot(ctx->slots[k], chunk * size_t(len), chunk);
         if (rc != SWMI_OK) return rc;
     }
     size_t idx = 0;
@@ -987,7 +1109,7 @@ int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
     std::lock_guard<std::mutex> lock(ctx->mu);
     // reuse slot 0: seq1 buffer holds the packed bytes, seq2 buffer the unpacked ones
     const size_t chunk = n_seqs < kChunkPairs ? n_seqs : kChunkPairs;
-    int rc = ensure_slot(ctx->slots[0], chunk);
+    int rc = ensure_slot(ctx->slots[0], chunk * kSeq, 0);
     if (rc != SWMI_OK) return rc;
     Slot &s = ctx->slots[0];
     hipError_t e = hipSuccess;
@@ -1003,23 +1125,27 @@ int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
     return SWMI_OK;
 }
 
-size_t swmi_host_granules(size_t n, size_t *granules, size_t cap)
+size_t swmi_host_granules_for(size_t n, int entry, size_t *granules, size_t cap)
 {
     {
         std::lock_guard<std::mutex> lock(g_init_mu);
         if (!g_knobs_read) read_knobs();
     }
+    if (entry < kEntryPairs || entry > kEntryOneVsMany) return 0;
+    const size_t per_pair = host_entry_bytes(entry), score_group = knobs().score_group;
     size_t count = 0;
-    for (size_t group = 0; group < n; group += kScoreGroup) {
-        const size_t group_n = n - group < kScoreGroup ? n - group : kScoreGroup;
+    for (size_t group = 0; group < n; group += score_group) {
+        const size_t group_n = n - group < score_group ? n - group : score_group;
         for (size_t off = 0; off < group_n; ++count) {
-            const size_t m = next_granule(group_n - off);
+            const size_t m = next_granule(group_n - off, per_pair);
             if (granules && count < cap) granules[count] = m;
             off += m;
         }
     }
     return count;
 }
+
+size_t swmi_host_granules(size_t n, size_t *granules, size_t cap) { return swmi_host_granules_for(n, SWMI_ENTRY_PAIRS, granules, cap); }
 
 int swmi_selftest_pk_max3(unsigned long long *checked, unsigned long long *mismatches)
 {

@@ -5,9 +5,12 @@
 #include "swmi_internal.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace swmi {
@@ -16,9 +19,13 @@ namespace host {
 constexpr size_t kSeq = SWMI_SEQ_LEN;
 constexpr size_t kChunkPairs = size_t(1) << 20;      // largest host-batch pipeline granule: 1M pairs = 128 MiB per input array
 constexpr size_t kMinGranule = size_t(1) << 14;      // smallest one (the tail of a tapered schedule)
-constexpr size_t kScoreGroup = size_t(1) << 24;      // pairs whose scores return to the host in one copy (64 MiB)
+constexpr size_t kBalancedGranule = size_t(1) << 16; // the granule where copy and kernel take the same time (2-bit packed input)
+constexpr size_t kMaxTaper1024 = 820;                // steepest granule-to-granule ratio, in 1/1024 (0.8): beyond it a 1M-pair batch
+                                                     //   breaks into so many copy commands that their fixed cost outweighs the tail
+constexpr size_t kScoreGroup = size_t(1) << 24;      // pairs whose scores return to the host in one copy (64 MiB); Knobs::score_group
 constexpr size_t kMaxLaunchPairs = size_t(1) << 30;  // pairs per kernel launch (the kernel indexes pairs with uint32)
-constexpr int kSlots = 3;
+constexpr int kSlots = 6;                            // device input buffer sets of the host-batch pipeline: up to three per issuing thread
+constexpr int kHostThreads = 2;                      // host threads that issue a host batch's copies and kernels (Knobs::host_threads)
 constexpr size_t kPinPairs = 64;                     // host batches up to this size go through the pinned staging buffer
 
 // SWMI_* environment knobs -- experiment / rehearsal switches, none needed in production.  Read ONCE, by swmi_init*
@@ -27,9 +34,17 @@ constexpr size_t kPinPairs = 64;                     // host batches up to this 
 struct Knobs {
     size_t host_granule = 0;        // SWMI_HOST_GRANULE: fixed pipeline granule in pairs (0 = tapered schedule)
     bool host_serial = false;       // SWMI_HOST_SERIAL=1: round 2's pipeline (scores copied back behind every granule), for the A/B
+    unsigned host_taper_pct = 0;    // SWMI_HOST_TAPER: granule-to-granule ratio of the tapered schedule in percent (0 = derived from
+                                    //   the entry's bytes per pair, next_granule())
+    size_t host_min_granule = 0;    // SWMI_HOST_MIN_GRANULE: smallest granule of the tapered schedule (0 = kMinGranule)
+    int host_slots = 0;                 // SWMI_HOST_SLOTS: buffer sets per issuing thread (2 or 3; 0 = the entry's default)
+    int host_threads = 0;               // SWMI_HOST_THREADS: issuing threads (1 or 2; 0 = the entry's default): the calling thread alone issues a host batch (round 3's pipeline), for the A/B
+    size_t score_group = kScoreGroup;   // SWMI_TEST_SCORE_GROUP: pairs per score copy -- test-only, so that the several-group
+                                    //   branch of score_host_batch runs at sizes a test can afford
     unsigned extra_lds = 0;         // SWMI_EXTRA_LDS: unused dynamic LDS per workgroup (occupancy sweep, BASELINE config 3)
     int lanes = 0;                  // SWMI_LANES: initial schedule
     bool banded_no_i16 = false;     // SWMI_BANDED_NO_I16
+    bool banded_no_pk = false;      // SWMI_BANDED_NO_PK: never the packed banded-affine kernel (A/B against the int32 cell)
     int sg_sweep = -1;              // SWMI_SG_SWEEP: force a semi-global sweep mapping (sg_kernels.hip choose_sweep)
     bool gather_p2p = false;        // SWMI_GATHER_BACKEND=p2p: never RCCL
     size_t gather_piece = 0;        // SWMI_TEST_GATHER_PIECE: ragged RCCL gather even for equal shards, shards broadcast in
@@ -42,9 +57,15 @@ void read_knobs();                  // (re)reads the environment; callers hold t
 struct Slot {
     hipStream_t stream = nullptr;
     uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr;
-    int32_t *d_scores = nullptr;
-    size_t capacity = 0;   // pairs
+    size_t capacity = 0;            // bytes of each of the two input buffers
+    int32_t *d_scores = nullptr;    // only the banded-affine host entry keeps per-slot scores (the 128x128 pipeline writes
+    size_t score_capacity = 0;      //   into Context::d_scores_all); capacity in scores
 };
+
+// What a host-batch entry ships per pair (next_granule derives the pipeline's taper from it)
+enum HostEntry { kEntryPairs = 0, kEntryPacked = 1, kEntryOneVsMany = 2 };
+size_t host_entry_bytes(int entry);                 // 256 / 64 / 128
+size_t next_granule(size_t remaining, size_t bytes_per_pair);
 
 // device buffers of the host-buffer semi-global entry (two chunks in flight), kept between calls and grown on demand
 struct SgSet {
@@ -54,6 +75,58 @@ struct SgSet {
     uint32_t *d_len = nullptr;
     size_t alignments = 0, tb_entries = 0;      // capacity
     size_t off = 0, m = 0;                      // chunk in flight
+};
+
+// A PERSISTENT host thread that runs one job at a time: a thread's first HIP call costs ~1 ms of runtime set-up, which a
+// thread spawned per call would pay every time.  swmi_multi.cpp keeps one per bound GPU beyond the first (the host-array
+// entry points over several GPUs), every Context one for the second half of its host-batch pipeline (score_host_batch).
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, stop = false;
+    Worker() { th = std::thread([this] { loop(); }); }
+    ~Worker() { shut(); }               // also at process exit without swmi_shutdown(): a joinable std::thread must not be destroyed
+    Worker(const Worker &) = delete;
+    Worker &operator=(const Worker &) = delete;
+    void shut()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            cv.wait(l, [this] { return has_job || stop; });
+            if (has_job) {              // (a job handed over before the stop still runs: its submitter waits for it)
+                l.unlock();
+                job();
+                l.lock();
+                has_job = false;
+                cv.notify_all();
+                continue;
+            }
+            return;                     // stop, nothing pending
+        }
+    }
+    void submit(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> l(mu);
+        job = std::move(f);
+        has_job = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [this] { return !has_job; });
+    }
 };
 
 struct Workspace {
@@ -75,6 +148,7 @@ struct Context {
     int32_t *d_scores_all = nullptr;    // host-batch pipeline: scores of one group of granules (up to kScoreGroup pairs)
     size_t scores_all_capacity = 0;
     hipEvent_t slot_done[kSlots] = {};  // recorded behind a slot's last kernel of a group
+    std::unique_ptr<Worker> copier;     // second issuing thread of the host-batch pipeline, created by the first batch that uses it
     SgSet sg_sets[2];
     // Semi-global device entry: one workspace per caller stream, so that calls on different streams may be in flight at
     // once; a workspace only grows (after synchronising ITS stream), and is looked up, grown and handed to the launch

@@ -40,7 +40,10 @@ hipError_t launch_score_one_vs_many(const LaunchConfig &cfg, const uint8_t *d_se
 // Banded (128 diagonals) affine-gap local alignment of n pairs of `len`-mers (device pointers).
 hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, int32_t *d_scores, size_t n, int len,
                                 const SmRows &rows, int gap_open, int gap_ext, hipStream_t stream,
-                                bool allow_i16 = true);     // false: never the 16-bit-max build (SWMI_BANDED_NO_I16, A/B)
+                                bool allow_i16 = true,      // false: never the 16-bit-max build (SWMI_BANDED_NO_I16, A/B)
+                                bool allow_pk = true);      // false: never the packed kernel (SWMI_BANDED_NO_PK, A/B)
+// 2 = sw_banded_affine_pk_kernel (two alignments per wavefront), 1 = the int32 cell with 16-bit maxes, 0 = the int32 cell
+int banded_affine_kernel_choice(int len, const SmRows &rows, int gap_open, int gap_ext, bool allow_i16, bool allow_pk);
 hipError_t launch_generate(uint8_t *d_seq1s, uint8_t *d_seq2s, size_t n, uint64_t seed, uint64_t first_pair,
                            hipStream_t stream);
 // Exhaustive check that v_pk_maximum3_f16 is a packed integer max on [0, 0x7C00)^2 (d_counts: two zeroed 64-bit words:

@@ -41,9 +41,14 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_rccl_mu;
 
-bool load_rccl()
+// `why` (optional) receives the reason under the same lock that guards g_rccl
+bool load_rccl(std::string *why = nullptr)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
+    struct Report {                                 // every exit leaves the reason with the caller
+        std::string *dst;
+        ~Report() { if (dst) *dst = g_rccl.why; }
+    } report{why};
     if (g_rccl.tried) return g_rccl.handle != nullptr;
     g_rccl.tried = true;
     const char *override_lib = knobs().rccl_lib[0] ? knobs().rccl_lib : nullptr;       // SWMI_RCCL_LIB
@@ -86,62 +91,16 @@ void shard_bounds(size_t n, int g, int G, size_t *lo, size_t *hi)
     *hi = l + base + (size_t(g) < extra ? 1 : 0);
 }
 
-// One PERSISTENT host thread per bound GPU for the host-array entry points: a thread's first HIP call costs ~1 ms of runtime
-// set-up, which a thread spawned per call would pay every time (round 2 did: 6.1 ms for a 1M-pair call that takes 4.7 ms on the
-// calling thread) -- and with eight GPUs a shard's whole copy is shorter than that.  Created on first use, joined by
+// One PERSISTENT host thread (swmi_host.h Worker) per bound GPU beyond the first for the host-array entry points -- spawned
+// per call, as in round 2, a 1M-pair call took 6.1 ms instead of 4.7: with eight GPUs a shard's whole copy is shorter than a
+// thread's first HIP call.  Shard 0 runs on the calling thread, so index 0 stays empty.  Created on first use, joined by
 // swmi_shutdown (stop_workers).
-struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, stop = false;
-    ~Worker() { shut(); }               // also at process exit without swmi_shutdown(): a joinable std::thread must not be destroyed
-    void shut()
-    {
-        {
-            std::lock_guard<std::mutex> l(mu);
-            stop = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
-    void loop()
-    {
-        std::unique_lock<std::mutex> l(mu);
-        for (;;) {
-            cv.wait(l, [this] { return has_job || stop; });
-            if (stop) return;
-            l.unlock();
-            job();
-            l.lock();
-            has_job = false;
-            cv.notify_all();
-        }
-    }
-    void submit(std::function<void()> f)
-    {
-        std::lock_guard<std::mutex> l(mu);
-        job = std::move(f);
-        has_job = true;
-        cv.notify_all();
-    }
-    void wait()
-    {
-        std::unique_lock<std::mutex> l(mu);
-        cv.wait(l, [this] { return !has_job; });
-    }
-};
 std::vector<std::unique_ptr<Worker>> g_workers;
 std::mutex g_workers_mu;                // one multi-GPU host batch at a time (they would serialise on the contexts anyway)
 
 void ensure_workers(int G)
 {
-    while ((int)g_workers.size() < G) {
-        g_workers.emplace_back(new Worker);
-        Worker *w = g_workers.back().get();
-        w->th = std::thread([w] { w->loop(); });
-    }
+    while ((int)g_workers.size() < G) g_workers.emplace_back(g_workers.empty() ? nullptr : new Worker);     // [0]: the caller itself
 }
 
 int multi_host(const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out, bool packed)
@@ -199,8 +158,13 @@ namespace host {
 void stop_workers()
 {
     std::lock_guard<std::mutex> pool_lock(g_workers_mu);
-    for (auto &w : g_workers) w->shut();
+    for (auto &w : g_workers)
+        if (w) w->shut();
     g_workers.clear();
+    // a FAILED attempt to load librccl is forgotten, so that a re-init with another SWMI_RCCL_LIB tries again (a loaded
+    // library stays: communicators of live batches point into it)
+    std::lock_guard<std::mutex> rccl_lock(g_rccl_mu);
+    if (!g_rccl.handle) g_rccl.tried = false;
 }
 }  // namespace host
 }  // namespace swmi
@@ -266,8 +230,9 @@ void decide_rccl(swmi_sharded_batch *b)
                 return;
             }
     }
-    if (!load_rccl()) {
-        b->rccl_why = "librccl could not be loaded: " + g_rccl.why;
+    std::string why;
+    if (!load_rccl(&why)) {
+        b->rccl_why = "librccl could not be loaded: " + why;
         return;
     }
     b->comms.assign(G, nullptr);
@@ -549,8 +514,9 @@ int swmi_rccl_probe(char *why, size_t why_len)
         std::lock_guard<std::mutex> lock(init_mutex());
         if (num_contexts() == 0) read_knobs();          // before any init: take SWMI_RCCL_LIB from the environment now
     }
-    const bool ok = load_rccl();
-    if (why && why_len) snprintf(why, why_len, "%s", ok ? "" : g_rccl.why.c_str());
+    std::string reason;
+    const bool ok = load_rccl(&reason);
+    if (why && why_len) snprintf(why, why_len, "%s", ok ? "" : reason.c_str());
     return ok ? 1 : 0;
 }
 

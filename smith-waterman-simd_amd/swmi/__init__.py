@@ -79,10 +79,13 @@ def load():
                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
     lib.swmi_host_granules.argtypes = [sz, vp, sz]
     lib.swmi_host_granules.restype = sz
+    lib.swmi_host_granules_for.argtypes = [sz, ctypes.c_int, vp, sz]
+    lib.swmi_host_granules_for.restype = sz
     lib.swmi_selftest_pk_max3.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     lib.swmi_sharded_gather_note.argtypes = [vp, ctypes.c_char_p, sz]
     lib.swmi_rccl_probe.argtypes = [ctypes.c_char_p, sz]
     lib.swmi_score_kernel_for_batch.argtypes = [sz, vp, i8, ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int)]
+    lib.swmi_banded_affine_kernel_for.argtypes = [ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_int)]
     lib.swmi_semiglobal_kernels_for_batch.argtypes = [sz, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
     lib.swmi_score_pair.argtypes = [vp, vp, vp, i8]
     lib.swmi_score_batch.argtypes = [vp, vp, sz, vp, i8, vp]
@@ -221,11 +224,15 @@ def selftest_pk_max3():
     return checked.value, bad.value
 
 
-def host_granules(n):
-    """The pipeline granules swmi_score_batch cuts a host batch of n pairs into (needs no device)."""
-    count = load().swmi_host_granules(n, None, 0)
+ENTRY_PAIRS, ENTRY_PACKED, ENTRY_ONE_VS_MANY = 0, 1, 2
+
+
+def host_granules(n, entry=ENTRY_PAIRS):
+    """The pipeline granules a host-batch entry cuts n pairs into (needs no device): ENTRY_PAIRS = swmi_score_batch,
+    ENTRY_PACKED = swmi_score_batch_packed, ENTRY_ONE_VS_MANY = swmi_score_one_vs_many."""
+    count = load().swmi_host_granules_for(n, entry, None, 0)
     buf = (ctypes.c_size_t * max(count, 1))()
-    load().swmi_host_granules(n, buf, count)
+    load().swmi_host_granules_for(n, entry, buf, count)
     return [int(buf[k]) for k in range(count)]
 
 
@@ -372,6 +379,16 @@ def score_banded_affine(seq1s, seq2s, score_matrix, gap_open, gap_extend):
     _check(load().swmi_score_banded_affine(a.ctypes.data, b.ctypes.data, n, length, sm.ctypes.data, int(gap_open),
                                            int(gap_extend), out.ctypes.data))
     return out
+
+
+def banded_affine_kernel_for(length, score_matrix, gap_open, gap_extend):
+    """(kernel instantiation, alignments per wavefront) a banded-affine launch with these parameters runs (needs no device)."""
+    sm = _sm(score_matrix)
+    name = ctypes.create_string_buffer(128)
+    per = ctypes.c_int()
+    _check(load().swmi_banded_affine_kernel_for(int(length), sm.ctypes.data_as(ctypes.c_void_p), int(gap_open), int(gap_extend), name, 128,
+                                               ctypes.byref(per)))
+    return name.value.decode(), per.value
 
 
 def score_banded_affine_device(d_seq1s, d_seq2s, n, length, score_matrix, gap_open, gap_extend, d_scores, stream=0):

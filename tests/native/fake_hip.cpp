@@ -1,7 +1,9 @@
 // fake_hip.cpp -- TEST INFRASTRUCTURE ONLY: a recording stand-in for the HIP runtime and for the kernel launchers, so that the
 // product's HOST code (swmi_api.cpp, swmi_multi.cpp) can run its multi-GPU logic on a machine with no GPU at all:
-// FAKE_HIP_DEVICES "gfx950" devices whose memory is host memory, copies that happen at once, streams and events that only
-// carry an id, and swmi::launch_* stand-ins that write, as the "score" of a pair, the 32-bit number found in the first four
+// FAKE_HIP_DEVICES "gfx950" devices whose memory is host memory, copies that happen at once -- EXCEPT device-to-host copies on
+// a stream, which are held back until that stream (or the device, or an event) is synchronised and read the device buffer
+// THEN: a host pipeline that lets later kernels overwrite a score buffer before its copy-back has drained hands back wrong
+// scores here, as it would on hardware -- streams and events that only carry an id, and swmi::launch_* stand-ins that write, as the "score" of a pair, the 32-bit number found in the first four
 // bytes of its seq1 -- tests/native/multi_fake.cpp stores the global pair index there, so a gathered score vector must read
 // 0, 1, 2, ... whatever the sharding, the gather backend and the order of the calls.  Nothing here is linked into libswmi.so.
 #include <hip/hip_runtime_api.h>
@@ -21,7 +23,9 @@ std::mutex g_mu;
 std::vector<std::string> g_log;
 thread_local int t_device = 0;
 int g_next_id = 1;
-struct Handle { int id; int device; };       // a stream or an event
+struct Pending { void *dst; const void *src; size_t n; };
+struct Handle { int id; int device; std::vector<Pending> pending; };       // a stream (with its held-back D2H copies) or an event
+std::vector<Handle *> g_streams;
 void log(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void log(const char *fmt, ...)
 {
@@ -34,6 +38,17 @@ void log(const char *fmt, ...)
     g_log.emplace_back(buf);
 }
 int stream_id(hipStream_t s) { return s ? reinterpret_cast<Handle *>(s)->id : 0; }
+void drain(Handle *h)                        // callers hold no lock; a stream is driven by one thread at a time
+{
+    for (auto &p : h->pending) memmove(p.dst, p.src, p.n);
+    h->pending.clear();
+}
+void drain_all()
+{
+    std::vector<Handle *> all;
+    { std::lock_guard<std::mutex> l(g_mu); all = g_streams; }
+    for (Handle *h : all) drain(h);
+}
 int device_count()
 {
     const char *e = getenv("FAKE_HIP_DEVICES");
@@ -67,28 +82,47 @@ hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
 {
     std::lock_guard<std::mutex> l(g_mu);
-    *s = reinterpret_cast<hipStream_t>(new Handle{g_next_id++, t_device});
+    Handle *h = new Handle{g_next_id++, t_device, {}};
+    g_streams.push_back(h);
+    *s = reinterpret_cast<hipStream_t>(h);
     return hipSuccess;
 }
-hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<Handle *>(s); return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s)
+{
+    Handle *h = reinterpret_cast<Handle *>(s);
+    drain(h);
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        for (size_t k = 0; k < g_streams.size(); ++k)
+            if (g_streams[k] == h) { g_streams.erase(g_streams.begin() + k); break; }
+    }
+    delete h;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s)
+{
+    log("dev%d stream_sync stream%d", t_device, stream_id(s));
+    if (s) drain(reinterpret_cast<Handle *>(s));
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { drain_all(); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e)
 {
     std::lock_guard<std::mutex> l(g_mu);
-    *e = reinterpret_cast<hipEvent_t>(new Handle{g_next_id++, t_device});
+    *e = reinterpret_cast<hipEvent_t>(new Handle{g_next_id++, t_device, {}});
     return hipSuccess;
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<Handle *>(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { log("dev%d event_record ev%d stream%d", t_device, reinterpret_cast<Handle *>(e)->id, stream_id(s)); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { drain_all(); return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { log("dev%d stream_wait stream%d ev%d", t_device, stream_id(s), reinterpret_cast<Handle *>(e)->id); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s)
 {
-    memmove(dst, src, n);
     log("dev%d memcpy kind%d bytes%zu stream%d", t_device, (int)kind, n, stream_id(s));
+    if (kind == hipMemcpyDeviceToHost && s) reinterpret_cast<Handle *>(s)->pending.push_back(Pending{dst, src, n});
+    else memmove(dst, src, n);
     return hipSuccess;
 }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind kind) { return hipMemcpyAsync(dst, src, n, kind, nullptr); }
@@ -137,7 +171,8 @@ hipError_t launch_generate(uint8_t *s1, uint8_t *s2, size_t n, uint64_t, uint64_
     }
     return hipSuccess;
 }
-hipError_t launch_banded_affine(const uint8_t *, const uint8_t *, int32_t *, size_t, int, const SmRows &, int, int, hipStream_t, bool) { return hipSuccess; }
+hipError_t launch_banded_affine(const uint8_t *, const uint8_t *, int32_t *, size_t, int, const SmRows &, int, int, hipStream_t, bool, bool) { return hipSuccess; }
+int banded_affine_kernel_choice(int, const SmRows &, int, int, bool, bool) { return 0; }
 hipError_t launch_unpack(const uint8_t *, uint8_t *, size_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_pk_max3_selftest(unsigned long long *, hipStream_t) { return hipSuccess; }
 size_t semiglobal_workspace_bytes(size_t n) { return 64 * (n + 1); }

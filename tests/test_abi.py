@@ -178,7 +178,7 @@ def test_pack_helper_round_trips(swmi_mod, golden):
 def test_host_batch_granules(swmi_mod):
     """The pipeline schedule of swmi_score_batch (swmi_api.cpp next_granule): tapering granules, every pair exactly once,
     few copy commands, a small last granule so that almost no kernel time is left behind the last copy.  Needs no device."""
-    for k in ("SWMI_HOST_GRANULE", "SWMI_HOST_SERIAL"):
+    for k in ("SWMI_HOST_GRANULE", "SWMI_HOST_SERIAL", "SWMI_HOST_TAPER", "SWMI_HOST_MIN_GRANULE", "SWMI_TEST_SCORE_GROUP"):
         assert k not in os.environ
     assert swmi_mod.host_granules(0) == []
     assert swmi_mod.host_granules(1) == [1]
@@ -190,6 +190,23 @@ def test_host_batch_granules(swmi_mod):
         assert sum(g) == n and max(g) <= 1 << 20 and min(g[:-1] or [1 << 14]) >= 1 << 14
         assert g[-1] <= 1 << 14 or n <= 1 << 14 or len(g) == 1
         assert len(g) <= n // (1 << 20) + 16             # a handful of copy commands beyond the 1M-pair granules
+    # The schedule follows the entry's bytes per pair (swmi_api.cpp next_granule): the taper ratio is kernel time over copy
+    # time per pair, so that granule k's kernel is done when granule k + 1 has landed
+    assert swmi_mod.host_granules(1 << 20, swmi_mod.ENTRY_PAIRS) == swmi_mod.host_granules(1 << 20)
+    ovm = swmi_mod.host_granules(1 << 20, swmi_mod.ENTRY_ONE_VS_MANY)          # 128 B per pair: halves
+    assert ovm == [524288, 262144, 131072, 65536, 32768, 16384, 16384]
+    for entry, ratio_lo, ratio_hi in ((swmi_mod.ENTRY_PAIRS, 0.2, 0.3), (swmi_mod.ENTRY_ONE_VS_MANY, 0.45, 0.55)):
+        for n in (1 << 20, (1 << 22) + 4097, (1 << 24) + 12345):
+            g = swmi_mod.host_granules(n, entry)
+            assert sum(g) == n and max(g) <= 1 << 20
+            # inside one score group, away from the caps: consecutive granules shrink by the entry's ratio
+            body = [x for x in g[: g.index(min(g))] if x < 1 << 20]
+            ratios = [b / a for a, b in zip(body, body[1:]) if b < a and b > 4 * 16384]
+            assert all(ratio_lo <= r <= ratio_hi for r in ratios), (entry, n, ratios)
+    packed = swmi_mod.host_granules(1 << 20, swmi_mod.ENTRY_PACKED)              # 64 B per pair: copy and kernel are level
+    assert packed == [1 << 16] * 16                                              # ... equal granules, two issuing threads
+    assert swmi_mod.host_granules((1 << 22) + 5000, swmi_mod.ENTRY_PACKED) == [1 << 17] * 17 + [1 << 16] * 30 + [5000]
+    assert swmi_mod.host_granules(100, 7) == []                                  # unknown entry
 
 
 def test_rccl_probe_reports_a_missing_library(swmi_mod):

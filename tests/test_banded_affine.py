@@ -110,3 +110,58 @@ def test_gpu_banded_affine_batch_shapes_and_errors(gpu, oracle):
     with pytest.raises(gpu.SwmiError) as e:
         gpu.score_banded_affine(np.zeros((1, 128), np.uint8), np.zeros((1, 128), np.uint8), sm, -1, 1)
     assert e.value.code == gpu.ERR_DOMAIN
+
+
+def test_banded_affine_kernel_choice_needs_no_device(swmi_mod):
+    """swmi_banded_affine_kernel_for: the packed kernel (two alignments per wavefront, 16-bit halves) where every value stays
+    a finite half-precision pattern -- len * max(s) + 2 max(0, -min s) + open + extend + 64 < 0x7C00 -- else the int32 cell."""
+    k = swmi_mod.banded_affine_kernel_for
+    assert k(1024, match_matrix(2, -3), 5, 1) == ("sw_banded_affine_pk_kernel<1>", 2)
+    assert k(1024, match_matrix(2, -3), 1, 4) == ("sw_banded_affine_pk_kernel<0>", 2)
+    assert k(1792, match_matrix(10, -30), 15, 15) == ("sw_banded_affine_pk_kernel<1>", 2)      # 17920 + 60 + 30 + 64
+    assert k(1024, match_matrix(30, -30), 5, 1)[0] == "sw_banded_affine_pk_kernel<1>"          # 30720 + 60 + 6 + 64 = 30850 < 31744
+    assert k(1024, match_matrix(31, -30), 5, 1) == ("sw_banded_affine_kernel<1,1>", 1)         # 31744 + ...: too large, still < 2^15
+    assert k(1024, match_matrix(32, -30), 5, 1) == ("sw_banded_affine_kernel<1,0>", 1)         # 32768: the plain int32 cell
+    assert k(64, match_matrix(127, -127), 127, 0) == ("sw_banded_affine_pk_kernel<1>", 2)      # 8128 + 254 + 127 + 64
+    assert k(256, match_matrix(127, -127), 0, 127)[0] == "sw_banded_affine_kernel<0,1>"       # 32512 + 254 + 127 + 64 > 0x7C00, < 2^15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sm_go_ge, want_kernel", [
+    ((match_matrix(2, -3), 5, 1), "sw_banded_affine_pk_kernel<1>"),
+    ((match_matrix(2, -3), 1, 4), "sw_banded_affine_pk_kernel<0>"),
+    ((match_matrix(3, 1), 4, 2), "sw_banded_affine_pk_kernel<1>"),            # no negative score: bias 0
+    ((match_matrix(3, 1), 0, 6), "sw_banded_affine_pk_kernel<0>"),
+    ((match_matrix(1, -1), 0, 0), "sw_banded_affine_pk_kernel<1>"),           # free gaps
+    ((match_matrix(0, -128), 127, 127), "sw_banded_affine_pk_kernel<1>"),     # the largest bias, nothing ever scores
+    ((match_matrix(20, -128), 3, 127), "sw_banded_affine_pk_kernel<0>"),      # bias 128 above open: the floor is the bias
+    ((match_matrix(20, -2), 100, 127), "sw_banded_affine_pk_kernel<0>"),      # open above the bias: the floor is open
+    ((match_matrix(40, -30), 5, 1), "sw_banded_affine_kernel<1,0>"),          # outside the packed domain at len 1024
+])
+def test_gpu_banded_affine_every_kernel_by_name(gpu, oracle, sm_go_ge, want_kernel):
+    """Each cell body of the banded-affine extension against the oracle, the launch checked to run the kernel named: related
+    pairs, unrelated pairs, identical pairs, an offset beyond the band, odd batch sizes (the packed kernel's last wavefront
+    then scores one pair twice).  Parity unpinned by the reference (no affine gap there)."""
+    sm, go, ge = sm_go_ge
+    length = 1024 if "pk" not in want_kernel or go + ge < 200 else 512
+    name, per = gpu.banded_affine_kernel_for(length, sm, go, ge)
+    assert name == want_kernel and per == (2 if "_pk_" in name else 1)
+    rng = np.random.default_rng(abs(hash(want_kernel + str(go))) % 1000)
+    for n in (1, 2, 7, 64, 131):
+        a, b = _related(rng, n, length)
+        if n >= 7:
+            b[0] = rng.integers(0, 4, length, dtype=np.uint8)
+            a[1] = b[1]
+            b[2] = np.roll(a[2], 70)
+            a[3] = 0; b[3] = 0                                                 # homopolymers
+        got = gpu.score_banded_affine(a, b, sm, go, ge)
+        want = oracle.banded_affine(a, b, sm, go, ge)
+        assert np.array_equal(got, want), (name, n, int((got != want).sum()), got[:8], want[:8])
+    mats = [rng.integers(-128, 128, 16).astype(np.int8) for _ in range(6)]
+    for m in mats:                                                             # random matrices at a length that keeps them packed
+        m = np.clip(m, -128, 60).astype(np.int8)
+        o, e = (int(rng.integers(0, 128)), int(rng.integers(0, 128)))
+        a, b = _related(rng, 33, 256)
+        got = gpu.score_banded_affine(a, b, m, o, e)
+        want = oracle.banded_affine(a, b, m, o, e)
+        assert np.array_equal(got, want), (gpu.banded_affine_kernel_for(256, m, o, e), m, o, e, int((got != want).sum()))

@@ -160,3 +160,55 @@ def test_automatic_schedule_follows_the_batch_size(gpu, oracle):
     for n in (1, 17, 2048, 2049, 5121, 24577, 98305):                  # each side of every threshold, ragged sizes included
         a, b = oracle.generate(n, 4242, 77)
         assert np.array_equal(gpu.score_batch(a, b, sm, 15), oracle.batch(a, b, sm, 15)), n
+
+
+@pytest.mark.parametrize("threads", [2, 1])
+def test_host_batch_over_several_score_groups(gpu, oracle, threads):
+    """score_host_batch's several-group branch (swmi_api.cpp): a host batch above the score group (16M pairs in production)
+    returns every group's scores in one copy at the group's host offset and drains that copy before the next group's kernels
+    overwrite the device score vector.  SWMI_TEST_SCORE_GROUP makes a group 32K pairs so that five groups + a ragged tail fit
+    a test; all three host entries, with two issuing threads (the default) and with one (round 3's pipeline)."""
+    import os
+    n = 5 * 32768 + 4321
+    sm = match_matrix(10, -30)
+    a, b = oracle.generate(n, 777, 5)
+    want = oracle.batch(a, b, sm, 15)
+    want_ovm = oracle.batch(a, np.broadcast_to(b[0], a.shape).copy(), sm, 15)
+    gpu.shutdown()
+    os.environ["SWMI_TEST_SCORE_GROUP"] = "32768"            # knobs are read at swmi_init
+    os.environ["SWMI_HOST_THREADS"] = str(threads)
+    try:
+        gpu.init(0)
+        for entry in (gpu.ENTRY_PAIRS, gpu.ENTRY_PACKED, gpu.ENTRY_ONE_VS_MANY):
+            g = gpu.host_granules(n, entry)
+            assert sum(g) == n and max(g) <= 32768 and len(g) >= 6
+        for _ in range(2):                                     # the second call reuses every buffer
+            assert np.array_equal(gpu.score_batch(a, b, sm, 15), want)
+            assert np.array_equal(gpu.score_batch_packed(gpu.pack(a), gpu.pack(b), sm, 15), want)
+            assert np.array_equal(gpu.score_one_vs_many(a, b[0], sm, 15), want_ovm)
+        pinned_a, pinned_b = torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory()
+        out = gpu.score_batch(pinned_a.numpy(), pinned_b.numpy(), sm, 15)      # pinned input: no copy blocks the issuing threads
+        assert np.array_equal(out, want)
+    finally:
+        del os.environ["SWMI_TEST_SCORE_GROUP"]
+        del os.environ["SWMI_HOST_THREADS"]
+        gpu.shutdown()
+        gpu.init(0)
+        gpu.set_schedule(0, 0)
+
+
+def test_host_batch_entries_agree_with_one_and_two_issuing_threads(gpu, oracle):
+    """The per-entry granule schedules (256 / 64 / 128 bytes per pair over the link) and the two-thread issue order give the
+    scores of the oracle at a size with many granules, ragged."""
+    n = (1 << 20) + 777
+    sm = match_matrix(10, -30)
+    a, b = oracle.generate(n, 99, 3)
+    want = oracle.batch(a[:70000], b[:70000], sm, 15)
+    got = gpu.score_batch(a, b, sm, 15)
+    got_packed = gpu.score_batch_packed(gpu.pack(a), gpu.pack(b), sm, 15)
+    assert np.array_equal(got[:70000], want) and np.array_equal(got, got_packed)
+    tail = oracle.batch(a[-5000:], b[-5000:], sm, 15)
+    assert np.array_equal(got[-5000:], tail)
+    ovm = gpu.score_one_vs_many(a, b[0], sm, 15)
+    assert np.array_equal(ovm[:20000], oracle.batch(a[:20000], np.broadcast_to(b[0], (20000, 128)).copy(), sm, 15))
+    assert np.array_equal(ovm[-3000:], oracle.batch(a[-3000:], np.broadcast_to(b[0], (3000, 128)).copy(), sm, 15))

@@ -1,44 +1,72 @@
-"""Host-buffer entry swmi_score_batch (PCIe inclusive) under different pipeline settings, on the GPU box.
-SWMI_HOST_SERIAL=1 is round 2's order of issue (scores copied back behind every granule); the default is the tapered
-schedule of swmi_api.cpp next_granule(); SWMI_HOST_GRANULE=<pairs> fixes the granule.
-Usage: python tools/host_pipeline_experiment.py"""
+"""Host-buffer entries (PCIe inclusive) under different pipeline settings, on the GPU box: swmi_score_batch (256 B per pair
+over the link), swmi_score_batch_packed (64 B) and swmi_score_one_vs_many (128 B).
+SWMI_HOST_SERIAL=1 is round 2's order of issue (scores copied back behind every granule); the default is the per-entry tapered
+schedule of swmi_api.cpp next_granule(); SWMI_HOST_GRANULE=<pairs> fixes the granule, SWMI_HOST_TAPER=<percent> the
+granule-to-granule ratio, SWMI_HOST_MIN_GRANULE=<pairs> the smallest granule.
+Usage: python tools/host_pipeline_experiment.py [pairs|packed|ovm|all]"""
 import os, sys, time
 import numpy as np
-import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "smith-waterman-simd_amd"))
 import swmi
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
 sm = swmi.match_matrix(10, -30)
-settings = [("round 2 order (serial), 1M granules", {"SWMI_HOST_SERIAL": "1", "SWMI_HOST_GRANULE": str(1 << 20)}),
-            ("deferred D2H, 1M granules", {"SWMI_HOST_GRANULE": str(1 << 20)}),
-            ("deferred D2H, 512K granules", {"SWMI_HOST_GRANULE": str(1 << 19)}),
-            ("deferred D2H, 256K granules", {"SWMI_HOST_GRANULE": str(1 << 18)}),
-            ("deferred D2H, 128K granules", {"SWMI_HOST_GRANULE": str(1 << 17)}),
-            ("deferred D2H, 64K granules", {"SWMI_HOST_GRANULE": str(1 << 16)}),
-            ("tapered (default)", {})]
+KNOBS = ("SWMI_HOST_SERIAL", "SWMI_HOST_GRANULE", "SWMI_HOST_TAPER", "SWMI_HOST_MIN_GRANULE", "SWMI_HOST_THREADS", "SWMI_HOST_SLOTS")
+
+
+def fixed(g, threads=2, slots=3):
+    return ("fixed %dK granules, %d thread(s) x %d buffer sets" % (g >> 10, threads, slots),
+            {"SWMI_HOST_GRANULE": str(g), "SWMI_HOST_THREADS": str(threads), "SWMI_HOST_SLOTS": str(slots)})
+
+
+def taper(pct, smallest, threads=2):
+    return ("taper %d %%, smallest %dK, %d thread(s)" % (pct, smallest >> 10, threads),
+            {"SWMI_HOST_TAPER": str(pct), "SWMI_HOST_MIN_GRANULE": str(smallest), "SWMI_HOST_THREADS": str(threads)})
+
+
+R3 = {"SWMI_HOST_TAPER": "25", "SWMI_HOST_MIN_GRANULE": str(1 << 14), "SWMI_HOST_THREADS": "1", "SWMI_HOST_SLOTS": "3"}
+settings = {
+    "pairs": [("round 2 order (serial), 1M granules", {"SWMI_HOST_SERIAL": "1", "SWMI_HOST_GRANULE": str(1 << 20)}),
+              ("round 3 pipeline (one thread)", R3), fixed(1 << 18), fixed(1 << 17), taper(25, 1 << 14), taper(50, 1 << 15),
+              taper(35, 1 << 15, 1), taper(50, 1 << 15, 1), ("default", {})],
+    "packed": [("round 3 pipeline (256-byte taper, one thread)", R3),
+               fixed(1 << 18, 1), fixed(1 << 17, 1), fixed(1 << 17, 2, 2), fixed(1 << 17), fixed(3 << 15, 2, 2), fixed(3 << 15),
+               fixed(1 << 16, 2, 2), fixed(1 << 16), fixed(3 << 14, 2, 2), fixed(3 << 14), fixed(1 << 15), ("default", {})],
+    "ovm": [("round 3 pipeline (256-byte taper, one thread)", R3), fixed(1 << 17), taper(50, 1 << 14, 1), taper(50, 1 << 14),
+            taper(60, 1 << 15, 1), taper(70, 1 << 15, 1), ("default", {})],
+}
 sizes = [1 << 20, 1 << 22]
-h = {}
-want = {}
+data = {}
 for n in sizes:
     a, b = swmi.generate_pairs_host(n, 10000, 0)
-    h[n] = (a, b, torch.from_numpy(a).pin_memory(), torch.from_numpy(b).pin_memory())
-for label, env in settings:
-    for k in ("SWMI_HOST_SERIAL", "SWMI_HOST_GRANULE"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    swmi.init(0)
-    for n in sizes:
-        a, b, pa, pb = h[n]
-        for kind, (x, y) in (("pageable", (a, b)), ("pinned", (pa.numpy(), pb.numpy()))):
-            got = swmi.score_batch(x, y, sm, 15)
-            if n not in want:
-                want[n] = got
-            assert np.array_equal(got, want[n]), (label, n, kind, int((got != want[n]).sum()))
-            best = 1e9
-            for _ in range(5):
+    data[n] = {"pairs": (a, b), "packed": (swmi.pack(a), swmi.pack(b)), "ovm": (a, b[0].copy())}
+call = {"pairs": lambda x, y: swmi.score_batch(x, y, sm, 15), "packed": lambda x, y: swmi.score_batch_packed(x, y, sm, 15),
+        "ovm": lambda x, y: swmi.score_one_vs_many(x, y, sm, 15)}
+entry_id = {"pairs": swmi.ENTRY_PAIRS, "packed": swmi.ENTRY_PACKED, "ovm": swmi.ENTRY_ONE_VS_MANY}
+want = {}
+for entry in ("pairs", "packed", "ovm"):
+    if which not in ("all", entry):
+        continue
+    print("== %s" % entry, flush=True)
+    for label, env in settings[entry]:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        swmi.init(0)
+        for n in sizes:
+            x, y = data[n][entry]
+            got = call[entry](x, y)
+            key = (entry, n) if entry == "ovm" else ("pairs", n)
+            if key not in want:
+                want[key] = got
+            assert np.array_equal(got, want[key]), (label, n, int((got != want[key]).sum()))
+            times = []
+            for _ in range(7):
                 t0 = time.perf_counter()
-                swmi.score_batch(x, y, sm, 15)
-                best = min(best, time.perf_counter() - t0)
-            gran = swmi.host_granules(n)
-            print("%-36s n = %8d %-9s %8.3f ms  %7.1f M alignments/s   granules %s" % (
-                label, n, kind, best * 1e3, n / best / 1e6, gran if len(gran) <= 8 else "%d x ..%s" % (len(gran), gran[-4:])), flush=True)
-    swmi.shutdown()
+                call[entry](x, y)
+                times.append(time.perf_counter() - t0)
+            times.sort()
+            gran = swmi.host_granules(n, entry_id[entry])
+            print("%-36s n = %8d  min %7.3f  median %7.3f ms  %7.1f M alignments/s (median)  granules %s" % (
+                label, n, times[0] * 1e3, times[3] * 1e3, n / times[3] / 1e6,
+                gran if len(gran) <= 8 else "%d x %s..%s" % (len(gran), gran[:2], gran[-3:])), flush=True)
+        swmi.shutdown()

@@ -106,7 +106,7 @@ def disassemble(lib_path=DEFAULT_LIB):
     return out
 
 
-KERNEL_NAMES = ("sw128_lut_kernel", "sw128_pk_kernel", "sw128_kernel", "sw_banded_affine_kernel", "sw_banded_affine_tile_kernel",
+KERNEL_NAMES = ("sw128_lut_kernel", "sw128_pk_kernel", "sw128_kernel", "sw_banded_affine_pk_kernel", "sw_banded_affine_kernel", "sw_banded_affine_tile_kernel",
                 "sg_forward_split_kernel", "sg_forward_lane_kernel", "sg_walk_lane_kernel", "sg_expand_kernel",
                 "sg_pack_streams_kernel", "pk_max3_selftest_kernel", "generate_kernel", "unpack_kernel")
 
