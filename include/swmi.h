@@ -252,6 +252,20 @@ SWMI_API int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, s
  * different streams use different workspaces and may be in flight together, from any threads. */
 SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
                                           void *d_tracebacks, size_t cap, void *d_lengths, void *stream);
+/* The same alignment with the traceback returned as MOVES instead of positions (round 4): the list of source.cpp:1962-1975
+ * is 8 bytes per position, up to 262 KB per alignment, which made the host entry above 11 x slower than the device entry --
+ * it ships positions over PCIe.  The walk itself produces 2 bits per step: moves + k * SWMI_SG_MOVE_WORDS receives
+ * alignment k's steps in WALKING order (step 0 leaves the best cell, the last one arrives at (0, 0)), step t at bits
+ * 2 (t % 32) of word t / 32: 3 = diagonal (i - 1, j - 1), 2 = up (i - 1), 1 = left (j - 1); lengths[k] = positions of the
+ * reference's list = steps + 1; words past the last step are unspecified.  swmi_semiglobal_expand_moves() turns one
+ * alignment's moves into the reference's (i, j) list on the host (no device; `cap` positions at most) -- the C++ overload of
+ * swmi_compat.hpp does that on several threads.  The best cell is (number of steps with bit 1, number with bit 0). */
+#define SWMI_SG_MOVE_WORDS 1025
+SWMI_API int swmi_semiglobal_xdrop_moves(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
+                                         uint64_t *moves, uint32_t *lengths);
+SWMI_API int swmi_semiglobal_xdrop_moves_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,
+                                                void *d_moves, void *d_lengths, void *stream);
+SWMI_API int swmi_semiglobal_expand_moves(const uint64_t *moves, uint32_t length, int32_t *traceback, size_t cap);
 /* Which sweep kernel the aligner runs is chosen from the batch size; this overrides the choice, the
  * way swmi_set_schedule does for the scorer -- every mapping returns the same (score, traceback), tests/test_semiglobal.py
  * runs them all.  sweep: -1 = automatic, 4 / 2 / 1 = the band over 4 / 2 lanes or in one lane (16 / 32 / 64 alignments per

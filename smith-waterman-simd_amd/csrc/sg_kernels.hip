@@ -1034,9 +1034,11 @@ void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size
         snprintf(tb_name, tb_len, "sg_walk_lane_kernel + sg_expand_kernel");
 }
 
+size_t semiglobal_move_words() { return (size_t)kMoveWords; }
+
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
-                             hipEvent_t between, int compute_units, SgTuning tuning)
+                             hipEvent_t between, int compute_units, SgTuning tuning, unsigned long long *d_moves_out)
 {
     if (n == 0) return hipSuccess;
     char *ws = static_cast<char *>(d_workspace);
@@ -1044,7 +1046,9 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     uint32_t *top = reinterpret_cast<uint32_t *>(ws + codes_bytes(n));          // the band's move bits (kDirWords x n)
     int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + dirs_bytes(n));
     unsigned long long *streams = reinterpret_cast<unsigned long long *>(ws + codes_bytes(n) + dirs_bytes(n) + round16(n * sizeof(int4)));
-    unsigned long long *moves = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
+    // the walk's moves: into the workspace, or straight into the caller's buffer (the entries that return moves, not positions)
+    unsigned long long *moves = d_moves_out ? d_moves_out
+                                            : reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(streams) + streams_bytes(n));
     // (Cutting the batch into sub-batches so that traceback k overlaps sweep k+1 was tried and is slower: below ~16k
     // alignments the sweep is latency bound, and four short sweeps in sequence cost four times one.)
     const int sweep = choose_sweep(n, compute_units, tuning);
@@ -1080,8 +1084,9 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top, summary,
                        moves, d_scores, d_lengths);
-    hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
-                       d_tracebacks, (uint32_t)cap);
+    if (d_tracebacks || !d_moves_out)           // (moves only: the caller expands them itself, swmi_semiglobal_expand_moves)
+        hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
+                           d_tracebacks, (uint32_t)cap);
     return hipGetLastError();
 }
 

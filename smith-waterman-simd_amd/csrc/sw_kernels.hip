@@ -1037,9 +1037,25 @@ struct BandedPkParams {
     uint32_t bias2;            // B in both halves
     uint32_t fold2;            // |open - ext| in both halves
     uint32_t cost2;            // what a handed-over value loses on arrival (ext resp. open) in both halves
-    uint32_t floor2;           // the max3's spare operand C in both halves
+    uint32_t delta2;           // B - cost per half as ONE 32-bit addend (see the kernel): what a value gains crossing an iteration
+    uint32_t best_step;        // B in both halves, less the carry the low dword of the paired add always produces when B < cost
 };
 
+// The bias GROWS: a cell computed in iteration u of a trip carries the bias beta_u = (u + 1) B, so that
+//     M = max3(H_diag' + (s + B), E', F')        IS the next diagonal term's H' -- no "M -sat B" per cell:
+// H_diag' has the bias of the iteration before, the lookup adds B, and E', F' arrive with beta_u because
+//   * a value handed over inside an iteration loses `cost` (v_sub_u32 / v_sub_u32_dpp, as before),
+//   * a value handed over ACROSS an iteration gains B - cost: one addend per dword, d | d << 16 for d >= 0 and
+//     (-|d| & 0xFFFF) | ((-|d| - 1) & 0xFFFF) << 16 for d < 0 -- each half is >= |d| (the floors), so the low half always
+//     carries into the high one and the -1 absorbs it; the own-lane one of the two is the low dword of a v_lshl_add_u64
+//     whose high dword moves the running best along by B (best_step: B less that ever-present carry);
+//   * the max3 that forms a hand-over value floors it at beta_u + cost (an SGPR that steps by B per iteration), i.e. at the
+//     true value `cost`: after the receiver's subtraction E', F' >= beta_u -- true zero -- and since every cell takes one of
+//     E', F' from its own lane, M >= beta_u: the zero floor of local alignment without an instruction.
+// Every kTrip iterations the seven state registers go back by kTrip * B (plain subtractions: all of them are >= that).
+// Per cell and pair of alignments: perm, 1/2 paired add, max3, sat-sub (hm), 2 max3, 1/2 + 1/2 (paired) + 1 add / sub,
+// 1/2 max3 (best) = 8 (9 for open < ext), + 7 / (2 kTrip) for the trip's rebase.
+constexpr int kBandedTrip = 16;
 template <bool kOpenGeExt>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 sw_banded_affine_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__restrict__ seq2s, int32_t *__restrict__ scores,
@@ -1082,14 +1098,16 @@ sw_banded_affine_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__r
     const uint32_t *pb = bsel + lane;           // pb[u] = selector of column j, pb[u + 1] of column j + 1
     uint2 a_cur = pa[0];
     uint32_t b_cur = pb[0];
-    const unsigned bias2 = prm.bias2, fold2 = prm.fold2, cost2 = prm.cost2, floor2 = prm.floor2;
-    // the subtrahend of the lane-crossing subtractions sits in a VGPR (gfx9 DPP takes no SGPR operand) and is 0 in the lane
-    // whose source lane does not exist (that lane's DPP read yields 0)
-    const unsigned cost_left = lane == 0 ? 0u : cost2, cost_up = lane == 63 ? 0u : cost2;
-    unsigned best = bias2;
-    unsigned h0 = 0, h1 = 0;                    // H of the last cell on diagonals 2m / 2m + 1 (X low, Y high)
-    unsigned me0 = floor2, mf0 = floor2, me1 = floor2, mf1 = floor2;
-    auto hand_over = [&](unsigned m, unsigned e, unsigned f, unsigned &me, unsigned &mf) {
+    const unsigned bias2 = prm.bias2, fold2 = prm.fold2, cost2 = prm.cost2;
+    // the addend / subtrahend of the lane-crossing operations sits in a VGPR (gfx9 DPP takes no SGPR operand) and is 0 in the
+    // lane whose source lane does not exist (that lane's DPP read yields 0, and 0 stands for "nothing": every cell takes
+    // its other gap operand from its own lane)
+    const unsigned delta_left = lane == 0 ? 0u : prm.delta2, cost_up = lane == 63 ? 0u : cost2;
+    const unsigned long long own_step = (unsigned long long)prm.delta2 | ((unsigned long long)prm.best_step << 32);
+    unsigned best = 0;
+    unsigned h0 = 0, h1 = 0;                    // H' of the last cell on diagonals 2m / 2m + 1 (X low, Y high)
+    unsigned me0 = cost2, mf0 = cost2, me1 = cost2, mf1 = cost2;           // hand-over values at their floor (true value: cost)
+    auto hand_over = [&](unsigned m, unsigned e, unsigned f, unsigned floor2, unsigned &me, unsigned &mf) {
         if constexpr (kOpenGeExt) {
             const unsigned hm = ba_pk_sub_sat(m, fold2);
             me = ba_pk_max3(e, hm, floor2);
@@ -1100,48 +1118,54 @@ sw_banded_affine_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__r
             mf = ba_pk_max3(fm, m, floor2);
         }
     };
-    auto pair_of_steps = [&](uint32_t b_next) {
-        // both diagonal terms at once: (h0, h1) + (lookup of (i, j), lookup of (i, j + 1))
+    // one iteration = two anti-diagonal steps; floor2 = beta + cost of THIS iteration in both halves
+    auto pair_of_steps = [&](uint32_t b_next, unsigned floor2) {
+        // both diagonal terms at once: (h0, h1) + (lookup of (i, j), lookup of (i, j + 1)).  (Written as a C addition hipcc
+        // splits it again, so the instruction is named; no half ever carries: every sum stays below 0x7C00.)
         const unsigned p0 = __builtin_amdgcn_perm(a_cur.y, a_cur.x, b_cur), p1 = __builtin_amdgcn_perm(a_cur.y, a_cur.x, b_next);
-        // (written as a C addition hipcc splits it again -- a 64-bit add of (h0, 0) and a v_add_u32 for h1 -- so the instruction
-        // is named; no half ever carries: every sum stays below 0x7C00)
-        unsigned long long t;
+        unsigned long long t, fb;
         asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"((unsigned long long)h0 | ((unsigned long long)h1 << 32)),
                                                         "v"((unsigned long long)p0 | ((unsigned long long)p1 << 32)));
         const unsigned t0 = (unsigned)t, t1 = (unsigned)(t >> 32);
-        unsigned m0, m1;
-        {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal
-            const unsigned e = (unsigned)__builtin_amdgcn_update_dpp(0, (int)me1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - cost_left;
-            const unsigned f = mf1 - cost2;
-            m0 = ba_pk_max3(t0, e, f);
-            h0 = ba_pk_sub_sat(m0, bias2);
-            hand_over(m0, e, f, me0, mf0);
+        {   // even step: diagonal 2m, cell (i, j); left = lane m-1's odd diagonal, up = own odd diagonal -- both from the
+            // iteration before: + (B - cost); the own one shares its instruction with the running best's + B
+            const unsigned e = (unsigned)__builtin_amdgcn_update_dpp(0, (int)me1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) + delta_left;
+            asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(fb) : "v"((unsigned long long)mf1 | ((unsigned long long)best << 32)), "s"(own_step));
+            const unsigned f = (unsigned)fb;
+            best = (unsigned)(fb >> 32);
+            h0 = ba_pk_max3(t0, e, f);
+            hand_over(h0, e, f, floor2, me0, mf0);
         }
-        {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal
+        {   // odd step: diagonal 2m+1, cell (i, j+1); left = own even diagonal, up = lane m+1's even diagonal (this iteration's)
             const unsigned e = me0 - cost2;
             const unsigned f = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mf0, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) - cost_up;
-            m1 = ba_pk_max3(t1, e, f);
-            h1 = ba_pk_sub_sat(m1, bias2);
-            hand_over(m1, e, f, me1, mf1);
+            h1 = ba_pk_max3(t1, e, f);
+            hand_over(h1, e, f, floor2, me1, mf1);
         }
-        best = ba_pk_max3(best, m0, m1);
+        best = ba_pk_max3(best, h0, h1);
         b_cur = b_next;
+    };
+    auto rebase = [&](unsigned back2) {         // every state register goes back by the trip's bias growth (all are >= it)
+        h0 -= back2; h1 -= back2; me0 -= back2; mf0 -= back2; me1 -= back2; mf1 -= back2; best -= back2;
     };
     int u = 0;
 #pragma unroll 1
-    for (; u + 4 <= len; u += 4) {              // four iterations per trip: LDS offsets become immediates
-        const uint32_t b1 = pb[u + 1], b2 = pb[u + 2], b3 = pb[u + 3], b4 = pb[u + 4];
-        const uint2 a1 = pa[u + 1], a2 = pa[u + 2], a3 = pa[u + 3], a4 = pa[u + 4];
-        pair_of_steps(b1); a_cur = a1;
-        pair_of_steps(b2); a_cur = a2;
-        pair_of_steps(b3); a_cur = a3;
-        pair_of_steps(b4); a_cur = a4;
+    for (; u + kBandedTrip <= len; u += kBandedTrip) {
+#pragma unroll
+        for (int k = 0; k < kBandedTrip; ++k) {
+            const uint32_t b_next = pb[u + k + 1];
+            const uint2 a_next = pa[u + k + 1];
+            pair_of_steps(b_next, cost2 + (unsigned)(k + 1) * bias2);
+            a_cur = a_next;
+        }
+        rebase((unsigned)kBandedTrip * bias2);
     }
-    for (; u < len; ++u) {
+    for (; u < len; ++u) {                      // the last len % kTrip iterations: trips of one
         const uint32_t b_next = pb[u + 1];
         const uint2 a_next = pa[u + 1];
-        pair_of_steps(b_next);
+        pair_of_steps(b_next, cost2 + bias2);
         a_cur = a_next;
+        rebase(bias2);
     }
     int bx = (int)(best & 0xFFFFu), by = (int)(best >> 16);
 #pragma unroll
@@ -1151,9 +1175,8 @@ sw_banded_affine_pk_kernel(const uint8_t *__restrict__ seq1s, const uint8_t *__r
         by = by > oy ? by : oy;
     }
     if (lane == 0) {
-        const int b = (int)(bias2 & 0xFFFFu);
-        scores[pair_x] = bx - b;
-        if (pair_x + 1 < n) scores[pair_x + 1] = by - b;
+        scores[pair_x] = bx;
+        if (pair_x + 1 < n) scores[pair_x + 1] = by;
     }
 }
 
@@ -1289,7 +1312,7 @@ int banded_affine_kernel_choice(int len, const SmRows &rows, int gap_open, int g
             low = v < low ? v : low;
         }
     const long long bias = -low;
-    if (allow_pk && (long long)len * top + 2 * bias + gap_open + gap_ext + 64 < 0x7C00) return 2;
+    if (allow_pk && (long long)len * top + (kBandedTrip + 2) * bias + gap_open + gap_ext + 64 < 0x7C00) return 2;
     // 16-bit maxes are exact while no H can reach 2^15: H <= len * (largest score, at least 0)
     return (long long)len * top < 32768 && allow_i16 ? 1 : 0;
 }
@@ -1319,11 +1342,17 @@ hipError_t launch_banded_affine(const uint8_t *d_seq1s, const uint8_t *d_seq2s, 
         }
         const bool oge = gap_open >= gap_ext;
         const unsigned fold = (unsigned)(oge ? gap_open - gap_ext : gap_ext - gap_open), cost = (unsigned)(oge ? gap_ext : gap_open);
-        const unsigned floor_c = oge ? cost : (bias > cost ? bias : cost);
         prm.bias2 = bias * 0x10001u;
         prm.fold2 = fold * 0x10001u;
         prm.cost2 = cost * 0x10001u;
-        prm.floor2 = floor_c * 0x10001u;
+        if (bias >= cost) {                     // B - cost >= 0: a plain per-half addend
+            prm.delta2 = (bias - cost) * 0x10001u;
+            prm.best_step = prm.bias2;
+        } else {                                // negative: two's complement per half, the high half less the low half's carry
+            const unsigned d = cost - bias;
+            prm.delta2 = ((0x10000u - d) & 0xFFFFu) | (((0x10000u - d - 1u) & 0xFFFFu) << 16);
+            prm.best_step = prm.bias2 - 1u;     // ... which also reaches the running best in the paired add
+        }
         const dim3 grid((unsigned)blocks);
         if (oge) hipLaunchKernelGGL((sw_banded_affine_pk_kernel<true>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, prm);
         else     hipLaunchKernelGGL((sw_banded_affine_pk_kernel<false>), grid, block, lds, stream, d_seq1s, d_seq2s, d_scores, (uint32_t)n, len, prm);

@@ -71,6 +71,16 @@ void read_knobs()
     k.host_serial = num("SWMI_HOST_SERIAL", 0, 1, 0) != 0;
     k.host_taper_pct = (unsigned)num("SWMI_HOST_TAPER", 1, 99, 0);
     k.host_min_granule = (size_t)num("SWMI_HOST_MIN_GRANULE", 1024, (long long)kChunkPairs, 0);
+    if (const char *sched = getenv("SWMI_HOST_SCHEDULE")) {
+        int c = 0;
+        for (const char *q = sched; *q && c < 16;) {
+            char *end = nullptr;
+            const long long v = strtoll(q, &end, 10);
+            if (end == q) break;
+            if (v >= 1024 && v <= (long long)kChunkPairs) k.host_schedule[c++] = (size_t)v;
+            q = *end == ',' ? end + 1 : end;
+        }
+    }
     k.host_threads = (int)num("SWMI_HOST_THREADS", 1, kHostThreads, 0);
     k.host_slots = (int)num("SWMI_HOST_SLOTS", 2, kSlots / kHostThreads, 0);
     k.score_group = (size_t)num("SWMI_TEST_SCORE_GROUP", 4096, (long long)kScoreGroup, (long long)kScoreGroup);
@@ -263,12 +273,6 @@ size_t next_granule(size_t remaining, size_t bytes_per_pair)
 {
     const Knobs &kn = knobs();
     if (kn.host_granule) return remaining < kn.host_granule ? remaining : kn.host_granule;
-    if (bytes_per_pair * 15 <= 1024 && !kn.host_taper_pct) {       // f would exceed 15/16: copy and kernel are level
-        // equal granules, small ones: the end exposed is one granule's kernel, and with two issuing threads (score_host_batch)
-        // the fixed cost of a copy command hides under the other thread's copy; a long batch starts on larger ones
-        const size_t g = kn.host_min_granule ? kn.host_min_granule : remaining > 32 * kBalancedGranule ? 2 * kBalancedGranule : kBalancedGranule;
-        return remaining < g ? remaining : g;
-    }
     const size_t smallest = kn.host_min_granule ? kn.host_min_granule : kMinGranule;
     if (remaining <= smallest) return remaining;
     size_t f1024 = kn.host_taper_pct ? size_t(kn.host_taper_pct) * 1024 / 100 : 65536 / bytes_per_pair;
@@ -333,6 +337,60 @@ hipError_t issue_granules(Context &ctx, const std::vector<Granule> &list, size_t
 }
 }  // namespace
 
+// The granules of one score group.  Where the link is the bound (256 / 128 bytes per pair) the tapered schedule of
+// next_granule.  Where copy and kernel are LEVEL (the 2-bit packed entry, 64 bytes per pair: f would exceed 15/16) a taper
+// cannot work -- the kernel never gains on the copies -- and the batch ends at about
+//     (first granule's copy) + max(all copies, all kernels + a launch ramp of ~13 us per granule) + (last granule's kernel)
+// + the score copy: equal granules of 128 K pairs (8 per 1M pairs: below that the launch ramps and the ~20 us a copy
+// command costs its issuing thread add up, above it the two ends grow) between a short first and last one (32 K, 96 K).
+// Measured against equal granules of 32 K .. 512 K, tapers of 50 .. 94 % and other ramp shapes, one and two issuing threads,
+// two and three buffer sets per thread: profiles/r04_host_pipeline_experiment.txt.
+void granule_list(size_t group_n, size_t bytes_per_pair, std::vector<size_t> *out)
+{
+    out->clear();
+    const Knobs &kn = knobs();
+    if (kn.host_schedule[0]) {                         // explicit list (experiments): the last entry repeats
+        size_t k = 0;
+        for (size_t rem = group_n; rem;) {
+            const size_t want = kn.host_schedule[k], g = rem < want ? rem : want;
+            out->push_back(g);
+            rem -= g;
+            if (k + 1 < 16 && kn.host_schedule[k + 1]) ++k;
+        }
+        return;
+    }
+    const bool balanced = bytes_per_pair * 15 <= 1024;
+    if (balanced && !kn.host_granule && !kn.host_taper_pct) {
+        const size_t steady = kn.host_min_granule ? kn.host_min_granule : kBalancedGranule;
+        const size_t ramp[2] = {steady / 4, steady - steady / 4};     // 32 K, 96 K: together one steady granule
+        if (group_n < 4 * steady) {                             // too short for the shape: equal granules of half the size
+            for (size_t rem = group_n; rem;) {
+                const size_t g = rem < steady / 2 ? rem : steady / 2;
+                out->push_back(g);
+                rem -= g;
+            }
+            return;
+        }
+        out->push_back(ramp[0]);
+        out->push_back(ramp[1]);
+        const size_t middle = group_n - 2 * steady;
+        const size_t count = (middle + steady - 1) / steady;
+        for (size_t k = 0, done = 0; k < count; ++k) {          // near-equal: cut at multiples of 4096, the last takes the rest
+            const size_t upto = k + 1 == count ? middle : (middle * (k + 1) / count) & ~size_t(4095);
+            out->push_back(upto - done);
+            done = upto;
+        }
+        out->push_back(ramp[1]);
+        out->push_back(ramp[0]);
+        return;
+    }
+    for (size_t rem = group_n; rem;) {
+        const size_t g = next_granule(rem, bytes_per_pair);
+        out->push_back(g);
+        rem -= g;
+    }
+}
+
 int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap, int32_t *out,
                      bool packed, bool one_vs_many)
 {
@@ -342,9 +400,11 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
     const bool serial = knobs().host_serial;             // round 2's order of issue, for the A/B
     const size_t score_group = knobs().score_group;
     const size_t first_group = n < score_group ? n : score_group;
-    const size_t largest = next_granule(first_group, per_pair);       // granules only shrink within a group, and no group is larger
-    size_t first_count = 0;
-    for (size_t rem = first_group; rem; ++first_count) rem -= next_granule(rem, per_pair);
+    std::vector<size_t> sizes;
+    granule_list(first_group, per_pair, &sizes);                      // no later group is larger, so none has a larger granule
+    size_t largest = 0;
+    for (size_t g : sizes) largest = g > largest ? g : largest;
+    const size_t first_count = sizes.size();
     // issuing threads: two where copy and kernel are level (the 2-bit packed entry) and there is more than one granule; where
     // the link alone is the bound (256 / 128 bytes per pair) a second thread only makes the two threads' copies and kernels
     // compete (measured: profiles/r04_host_pipeline_experiment.txt)
@@ -352,7 +412,7 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
     const int want_threads = knobs().host_threads ? knobs().host_threads : balanced ? 2 : 1;
     const int threads = (serial || want_threads < 2 || first_count < 2) ? 1 : 2;
     // buffer sets: three per issuing thread (a thread's copies may run two granules ahead of its kernels)
-    const int per_thread = knobs().host_slots ? knobs().host_slots : 3;
+    const int per_thread = knobs().host_slots ? knobs().host_slots : threads == 2 ? 2 : 3;
     const int used_slots = threads == 2 ? 2 * per_thread : n > score_group || first_count > size_t(per_thread) ? per_thread : int(first_count);
     for (int k = 0; k < used_slots; ++k) {
         const int rc = ensure_slot(ctx.slots[k], largest * in_stride, 0);
@@ -378,10 +438,13 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
     for (size_t group = 0; group < n && e == hipSuccess; group += score_group) {
         const size_t group_n = n - group < score_group ? n - group : score_group;
         list.clear();
-        for (size_t off = 0; off < group_n;) {
-            const size_t m = next_granule(group_n - off, per_pair);
-            list.push_back(Granule{off, m});
-            off += m;
+        granule_list(group_n, per_pair, &sizes);
+        {
+            size_t off = 0;
+            for (size_t m : sizes) {
+                list.push_back(Granule{off, m});
+                off += m;
+            }
         }
         bool used_mine[kSlots] = {}, used_theirs[kSlots] = {};
         hipError_t e2 = hipSuccess;
@@ -506,6 +569,7 @@ void destroy_context(Context &c)
     c.sg_workspaces.clear();
     for (auto &g : c.sg_sets) {
         (void)hipFree(g.d1); (void)hipFree(g.d2); (void)hipFree(g.ws); (void)hipFree(g.d_scores); (void)hipFree(g.d_len); (void)hipFree(g.d_tb);
+        (void)hipFree(g.d_moves);
         g = SgSet{};
     }
     if (c.pin) (void)hipHostFree(c.pin);
@@ -927,13 +991,13 @@ int swmi_score_banded_affine(const uint8_t *seq1s, const uint8_t *seq2s, size_t 
 }
 
 static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_tracebacks,
-                             size_t cap, void *d_lengths, void *stream, hipEvent_t between)
+                             size_t cap, void *d_lengths, void *stream, hipEvent_t between, void *d_moves = nullptr)
 {
     if (n == 0) return SWMI_OK;
     if (!d_seq1s || !d_seq2s || !d_scores || !d_lengths || (!d_tracebacks && cap != 0))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
     if ((reinterpret_cast<uintptr_t>(d_seq1s) | reinterpret_cast<uintptr_t>(d_seq2s) | reinterpret_cast<uintptr_t>(d_scores) |
-         reinterpret_cast<uintptr_t>(d_lengths) | reinterpret_cast<uintptr_t>(d_tracebacks)) & 15)
+         reinterpret_cast<uintptr_t>(d_lengths) | reinterpret_cast<uintptr_t>(d_tracebacks) | reinterpret_cast<uintptr_t>(d_moves)) & 15)
         return fail(SWMI_ERR_ALIGNMENT, "device pointers must be 16-byte aligned (the kernels use 16-byte loads and 8-byte stores)");
     if (n > (size_t(1) << 18)) return fail(SWMI_ERR_INVALID_ARGUMENT, "at most 2^18 alignments per call (got %zu)", n);
     Context *ctx = current();
@@ -955,7 +1019,36 @@ static int semiglobal_device(const void *d_seq1s, const void *d_seq2s, size_t n,
     }
     HIP_TRY(swmi::launch_semiglobal(static_cast<const uint8_t *>(d_seq1s), static_cast<const uint8_t *>(d_seq2s), n, ws.ptr,
                                     static_cast<int32_t *>(d_scores), static_cast<int32_t *>(d_tracebacks), cap,
-                                    static_cast<uint32_t *>(d_lengths), st, between, ctx->prop.multiProcessorCount, sg_tuning()));
+                                    static_cast<uint32_t *>(d_lengths), st, between, ctx->prop.multiProcessorCount, sg_tuning(),
+                                    static_cast<unsigned long long *>(d_moves)));
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_xdrop_moves_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores, void *d_moves,
+                                       void *d_lengths, void *stream)
+{
+    if (n && !d_moves) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL device buffer with n = %zu", n);
+    return semiglobal_device(d_seq1s, d_seq2s, n, d_scores, nullptr, 0, d_lengths, stream, nullptr, d_moves);
+}
+
+// Host-side expansion of one alignment's moves into the reference's traceback (source.cpp:1962-1975: the (i, j) list in
+// ascending order from (0, 0)).  No device involved.  Move t sits at bits 2 (t % 32) of word t / 32, in WALKING order (move 0
+// leaves the best cell); the list therefore applies them last to first: 3 = diagonal, 2 = a row step, 1 = a column step.
+int swmi_semiglobal_expand_moves(const uint64_t *moves, uint32_t length, int32_t *traceback, size_t cap)
+{
+    if (!moves || (!traceback && cap)) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (length == 0 || length > SWMI_SG_MAX_TRACEBACK) return fail(SWMI_ERR_INVALID_ARGUMENT, "length %u outside [1, %d]", length, SWMI_SG_MAX_TRACEBACK);
+    const size_t count = length < cap ? length : cap;
+    int32_t i = 0, j = 0;
+    size_t k = 0;
+    if (count) { traceback[0] = 0; traceback[1] = 0; k = 1; }
+    for (int64_t t = int64_t(length) - 2; t >= 0 && k < count; --t, ++k) {
+        const unsigned code = unsigned(moves[t >> 5] >> (2 * (t & 31))) & 3u;
+        i += int32_t(code >> 1);
+        j += int32_t(code & 1u);
+        traceback[2 * k] = i;
+        traceback[2 * k + 1] = j;
+    }
     return SWMI_OK;
 }
 
@@ -1017,18 +1110,21 @@ int swmi_semiglobal_time_device(const void *d_seq1s, const void *d_seq2s, size_t
     return rc;
 }
 
-int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, int32_t *tracebacks,
-                          size_t cap, uint32_t *lengths)
+// Host arrays -> (scores, lengths) + either the positions (tracebacks, `cap` per alignment) or the walk's moves (moves_out,
+// SWMI_SG_MOVE_WORDS words per alignment).  Chunks of up to 8192 alignments on two sets of device buffers: while the host is busy
+// receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k + 1.  Only as much of every
+// alignment's result crosses the link as the chunk's longest path needs.
+static int semiglobal_host(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, int32_t *tracebacks, size_t cap,
+                           uint64_t *moves_out, uint32_t *lengths)
 {
     if (n == 0) return SWMI_OK;
-    if (!seq1s || !seq2s || !scores || !lengths || (!tracebacks && cap != 0))
+    if (!seq1s || !seq2s || !scores || !lengths || (!tracebacks && cap != 0 && !moves_out))
         return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
     Context *ctx = current();
     if (!ctx) return last_status();
     std::lock_guard<std::mutex> lock(ctx->mu);
     constexpr size_t kLen = SWMI_SG_LEN;
-    // Chunks of up to 8192 alignments (~0.29 MB of workspace + cap*8 B of output each), two sets of device buffers: while
-    // the host is busy receiving chunk k (a copy into pageable memory blocks the caller), the GPU works on chunk k+1.
+    const size_t move_words = swmi::semiglobal_move_words();
     const size_t chunk = n < 8192 ? n : 8192;
     using Set = SgSet;
     Set *sets = ctx->sg_sets;
@@ -1038,7 +1134,7 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     for (int k = 0; k < n_sets && e == hipSuccess; ++k) {
         Set &s = sets[k];
         s.off = s.m = 0;
-        const size_t tb_need = chunk * (cap ? cap : 1);
+        const size_t tb_need = moves_out ? 0 : chunk * (cap ? cap : 1);
         if (s.alignments < chunk) {
             (void)hipFree(s.d1); (void)hipFree(s.d2); (void)hipFree(s.ws); (void)hipFree(s.d_scores); (void)hipFree(s.d_len);
             s.d1 = s.d2 = nullptr; s.ws = nullptr; s.d_scores = nullptr; s.d_len = nullptr; s.alignments = 0;
@@ -1055,8 +1151,14 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
             e = hipMalloc(&s.d_tb, tb_need * 2 * sizeof(int32_t));
             if (e == hipSuccess) s.tb_entries = tb_need;
         }
+        if (e == hipSuccess && moves_out && s.move_rows < chunk) {
+            (void)hipFree(s.d_moves);
+            s.d_moves = nullptr; s.move_rows = 0;
+            e = hipMalloc(reinterpret_cast<void **>(&s.d_moves), chunk * move_words * sizeof(uint64_t));
+            if (e == hipSuccess) s.move_rows = chunk;
+        }
     }
-    // results of the chunk a set holds -> host; only as many positions per alignment as the longest path of the chunk has
+    // results of the chunk a set holds -> host; only as many positions / moves per alignment as the longest path of the chunk has
     auto drain = [&](int which) -> hipError_t {
         Set &s = sets[which];
         hipStream_t st = streams[which];
@@ -1064,13 +1166,20 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
         hipError_t r = hipMemcpyAsync(scores + s.off, s.d_scores, s.m * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipMemcpyAsync(lengths + s.off, s.d_len, s.m * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipStreamSynchronize(st);
-        if (r == hipSuccess && cap) {
+        if (r == hipSuccess && (cap || moves_out)) {
             size_t longest = 0;
             for (size_t k = 0; k < s.m; ++k) longest = lengths[s.off + k] > longest ? lengths[s.off + k] : longest;
-            if (longest > cap) longest = cap;
-            const size_t pitch = cap * 2 * sizeof(int32_t);
-            r = hipMemcpy2DAsync(tracebacks + s.off * cap * 2, pitch, s.d_tb, pitch, longest * 2 * sizeof(int32_t), s.m,
-                                 hipMemcpyDeviceToHost, st);
+            if (moves_out) {
+                const size_t pitch = move_words * sizeof(uint64_t);
+                const size_t words = longest > 1 ? (longest - 1 + 31) / 32 : 1;              // positions = moves + 1, 32 moves per word
+                r = hipMemcpy2DAsync(moves_out + s.off * move_words, pitch, s.d_moves, pitch, words * sizeof(uint64_t), s.m,
+                                     hipMemcpyDeviceToHost, st);
+            } else {
+                if (longest > cap) longest = cap;
+                const size_t pitch = cap * 2 * sizeof(int32_t);
+                r = hipMemcpy2DAsync(tracebacks + s.off * cap * 2, pitch, s.d_tb, pitch, longest * 2 * sizeof(int32_t), s.m,
+                                     hipMemcpyDeviceToHost, st);
+            }
             if (r == hipSuccess) r = hipStreamSynchronize(st);
         }
         s.m = 0;
@@ -1088,7 +1197,8 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
         e = hipMemcpyAsync(s.d1, seq1s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(s.d2, seq2s + off * kLen, s.m * kLen, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
-            e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, s.d_tb, cap, s.d_len, st, nullptr, ctx->prop.multiProcessorCount, sg_tuning());
+            e = swmi::launch_semiglobal(s.d1, s.d2, s.m, s.ws, s.d_scores, moves_out ? nullptr : s.d_tb, moves_out ? 0 : cap, s.d_len, st, nullptr,
+                                        ctx->prop.multiProcessorCount, sg_tuning(), moves_out ? s.d_moves : nullptr);
         if (e == hipSuccess && n_sets == 2) e = drain(turn ^ 1);         // the previous chunk, while this one computes
     }
     for (int k = 0; k < n_sets; ++k) {
@@ -1098,6 +1208,18 @@ int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, 
     }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "swmi_semiglobal_xdrop: %s", hipGetErrorString(e));
     return SWMI_OK;
+}
+
+int swmi_semiglobal_xdrop(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, int32_t *tracebacks,
+                          size_t cap, uint32_t *lengths)
+{
+    return semiglobal_host(seq1s, seq2s, n, scores, tracebacks, cap, nullptr, lengths);
+}
+
+int swmi_semiglobal_xdrop_moves(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores, uint64_t *moves, uint32_t *lengths)
+{
+    if (n && !moves) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer with n = %zu", n);
+    return semiglobal_host(seq1s, seq2s, n, scores, nullptr, 0, moves, lengths);
 }
 
 int swmi_unpack(const uint8_t *packed, size_t n_seqs, uint8_t *unpacked)
@@ -1134,12 +1256,13 @@ size_t swmi_host_granules_for(size_t n, int entry, size_t *granules, size_t cap)
     if (entry < kEntryPairs || entry > kEntryOneVsMany) return 0;
     const size_t per_pair = host_entry_bytes(entry), score_group = knobs().score_group;
     size_t count = 0;
+    std::vector<size_t> sizes;
     for (size_t group = 0; group < n; group += score_group) {
         const size_t group_n = n - group < score_group ? n - group : score_group;
-        for (size_t off = 0; off < group_n; ++count) {
-            const size_t m = next_granule(group_n - off, per_pair);
+        granule_list(group_n, per_pair, &sizes);
+        for (size_t m : sizes) {
             if (granules && count < cap) granules[count] = m;
-            off += m;
+            ++count;
         }
     }
     return count;

@@ -19,7 +19,7 @@ namespace host {
 constexpr size_t kSeq = SWMI_SEQ_LEN;
 constexpr size_t kChunkPairs = size_t(1) << 20;      // largest host-batch pipeline granule: 1M pairs = 128 MiB per input array
 constexpr size_t kMinGranule = size_t(1) << 14;      // smallest one (the tail of a tapered schedule)
-constexpr size_t kBalancedGranule = size_t(1) << 16; // the granule where copy and kernel take the same time (2-bit packed input)
+constexpr size_t kBalancedGranule = size_t(1) << 17; // the steady granule where copy and kernel take the same time (2-bit packed input)
 constexpr size_t kMaxTaper1024 = 820;                // steepest granule-to-granule ratio, in 1/1024 (0.8): beyond it a 1M-pair batch
                                                      //   breaks into so many copy commands that their fixed cost outweighs the tail
 constexpr size_t kScoreGroup = size_t(1) << 24;      // pairs whose scores return to the host in one copy (64 MiB); Knobs::score_group
@@ -37,6 +37,7 @@ struct Knobs {
     unsigned host_taper_pct = 0;    // SWMI_HOST_TAPER: granule-to-granule ratio of the tapered schedule in percent (0 = derived from
                                     //   the entry's bytes per pair, next_granule())
     size_t host_min_granule = 0;    // SWMI_HOST_MIN_GRANULE: smallest granule of the tapered schedule (0 = kMinGranule)
+    size_t host_schedule[16] = {};      // SWMI_HOST_SCHEDULE="a,b,c,...": explicit granule sizes (the last one repeats), experiments only
     int host_slots = 0;                 // SWMI_HOST_SLOTS: buffer sets per issuing thread (2 or 3; 0 = the entry's default)
     int host_threads = 0;               // SWMI_HOST_THREADS: issuing threads (1 or 2; 0 = the entry's default): the calling thread alone issues a host batch (round 3's pipeline), for the A/B
     size_t score_group = kScoreGroup;   // SWMI_TEST_SCORE_GROUP: pairs per score copy -- test-only, so that the several-group
@@ -66,6 +67,7 @@ struct Slot {
 enum HostEntry { kEntryPairs = 0, kEntryPacked = 1, kEntryOneVsMany = 2 };
 size_t host_entry_bytes(int entry);                 // 256 / 64 / 128
 size_t next_granule(size_t remaining, size_t bytes_per_pair);
+void granule_list(size_t group_n, size_t bytes_per_pair, std::vector<size_t> *out);   // the granules of one score group, in order
 
 // device buffers of the host-buffer semi-global entry (two chunks in flight), kept between calls and grown on demand
 struct SgSet {
@@ -73,7 +75,8 @@ struct SgSet {
     void *ws = nullptr;
     int32_t *d_scores = nullptr, *d_tb = nullptr;
     uint32_t *d_len = nullptr;
-    size_t alignments = 0, tb_entries = 0;      // capacity
+    unsigned long long *d_moves = nullptr;      // [alignments][SWMI_SG_MOVE_WORDS]: the entry that returns moves instead of positions
+    size_t alignments = 0, tb_entries = 0, move_rows = 0;      // capacity
     size_t off = 0, m = 0;                      // chunk in flight
 };
 

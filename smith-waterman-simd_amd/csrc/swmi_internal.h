@@ -63,7 +63,11 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,
                              hipEvent_t between = nullptr,    // recorded between the sweep and the traceback kernel
                              int compute_units = 256,         // of the device: picks the sweep mapping (wavefronts per SIMD)
-                             SgTuning tuning = SgTuning());
+                             SgTuning tuning = SgTuning(),
+                             unsigned long long *d_moves_out = nullptr);   // non-NULL: the walk's 2-bit moves go here
+                                                                           //   ([n][semiglobal_move_words()]); with d_tracebacks
+                                                                           //   NULL the expand kernel is skipped
+size_t semiglobal_move_words();                  // 64-bit words of moves per alignment (32 moves each)
 // Names of the sweep / traceback kernels launch_semiglobal picks for n alignments on a device with that many CUs.
 void semiglobal_kernel_names(size_t n, int compute_units, char *sweep_name, size_t sweep_len, char *tb_name, size_t tb_len,
                              SgTuning tuning = SgTuning());

@@ -203,9 +203,15 @@ def test_host_batch_granules(swmi_mod):
             body = [x for x in g[: g.index(min(g))] if x < 1 << 20]
             ratios = [b / a for a, b in zip(body, body[1:]) if b < a and b > 4 * 16384]
             assert all(ratio_lo <= r <= ratio_hi for r in ratios), (entry, n, ratios)
-    packed = swmi_mod.host_granules(1 << 20, swmi_mod.ENTRY_PACKED)              # 64 B per pair: copy and kernel are level
-    assert packed == [1 << 16] * 16                                              # ... equal granules, two issuing threads
-    assert swmi_mod.host_granules((1 << 22) + 5000, swmi_mod.ENTRY_PACKED) == [1 << 17] * 17 + [1 << 16] * 30 + [5000]
+    # 64 B per pair: copy and kernel are level -- equal granules of 128 K between a short first and last one, two issuing threads
+    packed = swmi_mod.host_granules(1 << 20, swmi_mod.ENTRY_PACKED)
+    assert packed == [32768, 98304] + [131072] * 6 + [98304, 32768]
+    for n in (524288, (1 << 22) + 5000, (1 << 24) + 5):
+        g = swmi_mod.host_granules(n, swmi_mod.ENTRY_PACKED)
+        group = g[: g.index(32768, 1) + 1]                                       # the first score group's granules
+        assert sum(g) == n and group[:2] == [32768, 98304] and group[-2:] == [98304, 32768]
+        assert all(126976 <= x <= 135168 for x in group[2:-2])
+    assert swmi_mod.host_granules(300000, swmi_mod.ENTRY_PACKED) == [65536] * 4 + [37856]     # too short for the shape
     assert swmi_mod.host_granules(100, 7) == []                                  # unknown entry
 
 

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import swmi
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 sm = swmi.match_matrix(10, -30)
-KNOBS = ("SWMI_HOST_SERIAL", "SWMI_HOST_GRANULE", "SWMI_HOST_TAPER", "SWMI_HOST_MIN_GRANULE", "SWMI_HOST_THREADS", "SWMI_HOST_SLOTS")
+KNOBS = ("SWMI_HOST_SERIAL", "SWMI_HOST_GRANULE", "SWMI_HOST_TAPER", "SWMI_HOST_MIN_GRANULE", "SWMI_HOST_THREADS", "SWMI_HOST_SLOTS", "SWMI_HOST_SCHEDULE")
 
 
 def fixed(g, threads=2, slots=3):
@@ -23,14 +23,22 @@ def taper(pct, smallest, threads=2):
             {"SWMI_HOST_TAPER": str(pct), "SWMI_HOST_MIN_GRANULE": str(smallest), "SWMI_HOST_THREADS": str(threads)})
 
 
+def sched(ks, threads=2, slots=2):
+    return ("schedule %s K, %d thread(s) x %d sets" % (",".join(str(k) for k in ks), threads, slots),
+            {"SWMI_HOST_SCHEDULE": ",".join(str(k << 10) for k in ks), "SWMI_HOST_THREADS": str(threads), "SWMI_HOST_SLOTS": str(slots)})
+
+
 R3 = {"SWMI_HOST_TAPER": "25", "SWMI_HOST_MIN_GRANULE": str(1 << 14), "SWMI_HOST_THREADS": "1", "SWMI_HOST_SLOTS": "3"}
 settings = {
     "pairs": [("round 2 order (serial), 1M granules", {"SWMI_HOST_SERIAL": "1", "SWMI_HOST_GRANULE": str(1 << 20)}),
               ("round 3 pipeline (one thread)", R3), fixed(1 << 18), fixed(1 << 17), taper(25, 1 << 14), taper(50, 1 << 15),
               taper(35, 1 << 15, 1), taper(50, 1 << 15, 1), ("default", {})],
     "packed": [("round 3 pipeline (256-byte taper, one thread)", R3),
-               fixed(1 << 18, 1), fixed(1 << 17, 1), fixed(1 << 17, 2, 2), fixed(1 << 17), fixed(3 << 15, 2, 2), fixed(3 << 15),
-               fixed(1 << 16, 2, 2), fixed(1 << 16), fixed(3 << 14, 2, 2), fixed(3 << 14), fixed(1 << 15), ("default", {})],
+               fixed(1 << 18, 1), fixed(1 << 17, 2, 2), fixed(1 << 16, 2, 2),
+               sched([64, 128, 192, 256, 192, 128, 64]), sched([32, 64, 128, 256, 256, 128, 96, 64]), sched([64, 128, 256, 256, 192, 128]),
+               sched([32, 64, 96, 128, 160, 160, 128, 96, 64, 48, 32, 16]), sched([16, 32, 64, 128, 256, 256, 128, 64, 48, 32]),
+               sched([32, 64, 128, 192, 192, 192, 128, 64, 32], 1, 3), sched([32, 64, 128, 192, 192, 192, 128, 64, 32], 2, 3),
+               sched([32, 96, 128, 128, 128, 128, 128, 128, 96, 32]), ("default", {})],
     "ovm": [("round 3 pipeline (256-byte taper, one thread)", R3), fixed(1 << 17), taper(50, 1 << 14, 1), taper(50, 1 << 14),
             taper(60, 1 << 15, 1), taper(70, 1 << 15, 1), ("default", {})],
 }
