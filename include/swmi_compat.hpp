@@ -12,6 +12,8 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "swmi.h"
@@ -25,7 +27,53 @@ inline int SmithWaterman_mi355x(const std::array<uint8_t, 128> &seq1, const std:
     return r;
 }
 
+// Same arguments, same return value as SemiGlobal_AdaptiveBanded_XDrop_111_32_70 and its _simd / _simd_mark2..4 variants
+// (source.cpp:1836-1838, :1978, call sites TestSemiGlobal :2774-2778, SpeedtestSemiGlobal :2818-2856): (score, traceback from
+// (0, 0) to the best cell).  One synchronous call per alignment -- correct, but ~11 ms of latency each: use the batch below.
+inline std::pair<int, std::vector<std::pair<int, int>>> SemiGlobal_AdaptiveBanded_XDrop_mi355x(const std::array<uint8_t, 16384> &seq1,
+                                                                                              const std::array<uint8_t, 16384> &seq2);
+
 namespace swmi {
+
+// One alignment's moves (swmi_semiglobal_xdrop_moves) -> the reference's traceback vector (source.cpp:1962-1975).
+inline std::vector<std::pair<int, int>> expand_moves(const uint64_t *moves, uint32_t length)
+{
+    static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int32_t), "std::pair<int,int> must be two packed ints");
+    std::vector<std::pair<int, int>> tb(length);
+    if (swmi_semiglobal_expand_moves(moves, length, reinterpret_cast<int32_t *>(tb.data()), length) != SWMI_OK)
+        throw std::runtime_error(std::string("swmi_semiglobal_expand_moves: ") + swmi_last_error());
+    return tb;
+}
+
+// The reference's SpeedtestSemiGlobal loop (source.cpp:2818-2856) over arrays of pairs: result[k] ==
+// SemiGlobal_AdaptiveBanded_XDrop_111_32_70(seq1s[k], seq2s[k]).  The GPU returns 2 bits per traceback step (8 KB per
+// alignment over PCIe instead of the 262 KB its positions take); the positions are rebuilt here, on `threads` host threads
+// (0 = as many as the machine reports, at most 64).
+inline std::vector<std::pair<int, std::vector<std::pair<int, int>>>> SemiGlobal_mi355x_batch(
+    const std::vector<std::array<uint8_t, 16384>> &seq1s, const std::vector<std::array<uint8_t, 16384>> &seq2s, unsigned threads = 0)
+{
+    static_assert(sizeof(std::array<uint8_t, 16384>) == 16384, "std::array<uint8_t,16384> must be 16384 contiguous bytes");
+    if (seq1s.size() != seq2s.size()) throw std::invalid_argument("SemiGlobal_mi355x_batch: seq1s and seq2s differ in length");
+    const size_t n = seq1s.size();
+    std::vector<std::pair<int, std::vector<std::pair<int, int>>>> out(n);
+    if (n == 0) return out;
+    std::vector<int32_t> scores(n);
+    std::vector<uint32_t> lengths(n);
+    std::vector<uint64_t> moves(n * size_t(SWMI_SG_MOVE_WORDS));
+    if (swmi_semiglobal_xdrop_moves(seq1s[0].data(), seq2s[0].data(), n, scores.data(), moves.data(), lengths.data()) != SWMI_OK)
+        throw std::runtime_error(std::string("swmi_semiglobal_xdrop_moves: ") + swmi_last_error());
+    if (threads == 0) threads = std::thread::hardware_concurrency();
+    threads = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    if (threads > n) threads = unsigned(n);
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) out[k] = {scores[k], expand_moves(moves.data() + k * size_t(SWMI_SG_MOVE_WORDS), lengths[k])};
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
+    work(0, n / threads);
+    for (auto &th : pool) th.join();
+    return out;
+}
 
 // The reference's 1M-call loop (source.cpp:3074-3082) over arrays of pairs, on every GPU the library is bound to:
 // scores[k] == SmithWaterman(seq1s[k], seq2s[k], score_matrix, gap_penalty).  std::array<uint8_t,128> has no padding, so a
@@ -79,3 +127,14 @@ private:
 };
 
 }  // namespace swmi
+
+inline std::pair<int, std::vector<std::pair<int, int>>> SemiGlobal_AdaptiveBanded_XDrop_mi355x(const std::array<uint8_t, 16384> &seq1,
+                                                                                              const std::array<uint8_t, 16384> &seq2)
+{
+    int32_t score = 0;
+    uint32_t length = 0;
+    std::vector<uint64_t> moves(SWMI_SG_MOVE_WORDS);
+    if (swmi_semiglobal_xdrop_moves(seq1.data(), seq2.data(), 1, &score, moves.data(), &length) != SWMI_OK)
+        throw std::runtime_error(std::string("swmi_semiglobal_xdrop_moves: ") + swmi_last_error());
+    return {score, swmi::expand_moves(moves.data(), length)};
+}

@@ -1039,15 +1039,16 @@ int swmi_semiglobal_expand_moves(const uint64_t *moves, uint32_t length, int32_t
     if (!moves || (!traceback && cap)) return fail(SWMI_ERR_INVALID_ARGUMENT, "NULL buffer");
     if (length == 0 || length > SWMI_SG_MAX_TRACEBACK) return fail(SWMI_ERR_INVALID_ARGUMENT, "length %u outside [1, %d]", length, SWMI_SG_MAX_TRACEBACK);
     const size_t count = length < cap ? length : cap;
-    int32_t i = 0, j = 0;
-    size_t k = 0;
-    if (count) { traceback[0] = 0; traceback[1] = 0; k = 1; }
-    for (int64_t t = int64_t(length) - 2; t >= 0 && k < count; --t, ++k) {
-        const unsigned code = unsigned(moves[t >> 5] >> (2 * (t & 31))) & 3u;
-        i += int32_t(code >> 1);
-        j += int32_t(code & 1u);
-        traceback[2 * k] = i;
-        traceback[2 * k + 1] = j;
+    if (count == 0) return SWMI_OK;
+    // position k as ONE 64-bit word (i in the low half, j in the high half: two int32 on a little-endian host); a step adds its
+    // row / column increment to it.  Step t of the walk produces position length - 1 - t of the list.
+    static const uint64_t kStep[4] = {0, uint64_t(1) << 32, 1, (uint64_t(1) << 32) | 1};
+    uint64_t pos = 0;
+    memcpy(traceback, &pos, sizeof pos);                 // (traceback need not be 8-byte aligned)
+    int64_t t = int64_t(length) - 2;
+    for (size_t k = 1; k < count; ++k, --t) {
+        pos += kStep[(moves[t >> 5] >> (2 * (t & 31))) & 3u];
+        memcpy(traceback + 2 * k, &pos, sizeof pos);
     }
     return SWMI_OK;
 }

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -158,6 +159,36 @@ int main(int argc, char **argv)
         const double ms = now_ms() - t0;
         printf("mi355x batch version: %.0f ms / %zuK incl. PCIe  (score %d, %u traceback positions, %.1f k alignments/s)\n", ms,
                n_sg / 1000, scores[0], lengths[0], n_sg / ms);
+        {   // the same call with the traceback as 2-bit moves (8 KB per alignment back over the link instead of 262 KB), and
+            // the positions rebuilt on the host, as swmi_compat.hpp's SemiGlobal_mi355x_batch does it
+            std::vector<uint64_t> moves(n_sg * size_t(SWMI_SG_MOVE_WORDS));
+            std::vector<int32_t> sc2(n_sg);
+            std::vector<uint32_t> len2(n_sg);
+            if (swmi_semiglobal_xdrop_moves(s1.data(), s2.data(), n_sg, sc2.data(), moves.data(), len2.data()) != SWMI_OK) die("swmi_semiglobal_xdrop_moves");
+            const double t1 = now_ms();
+            if (swmi_semiglobal_xdrop_moves(s1.data(), s2.data(), n_sg, sc2.data(), moves.data(), len2.data()) != SWMI_OK) die("swmi_semiglobal_xdrop_moves");
+            const double ms_moves = now_ms() - t1;
+            printf("mi355x batch version, traceback as moves: %.0f ms / %zuK incl. PCIe  (%.1f k alignments/s)\n", ms_moves, n_sg / 1000, n_sg / ms_moves);
+            const unsigned hw = std::thread::hardware_concurrency();
+            for (unsigned threads : {1u, 4u, 16u, hw > 16 ? (hw > 64 ? 64u : hw) : 0u}) {
+                if (!threads) continue;
+                std::vector<int32_t> tb2(n_sg * kCap * 2);
+                const double t2 = now_ms();
+                std::vector<std::thread> pool;
+                auto work = [&](size_t lo, size_t hi) {
+                    for (size_t k = lo; k < hi; ++k)
+                        swmi_semiglobal_expand_moves(&moves[k * size_t(SWMI_SG_MOVE_WORDS)], len2[k], &tb2[k * kCap * 2], kCap);
+                };
+                for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work, n_sg * t / threads, n_sg * (t + 1) / threads);
+                work(0, n_sg / threads);
+                for (auto &th : pool) th.join();
+                const double ms_exp = now_ms() - t2;
+                const bool same = sc2 == scores && len2 == lengths && memcmp(tb2.data(), tb.data(), size_t(lengths[0]) * 8) == 0 &&
+                                  memcmp(&tb2[(n_sg - 1) * kCap * 2], &tb[(n_sg - 1) * kCap * 2], size_t(lengths[n_sg - 1]) * 8) == 0;
+                printf("   host expansion of the moves on %2u thread(s): %.0f ms / %zuK (%.1f k alignments/s); moves + expansion %.1f k alignments/s; %s\n",
+                       threads, ms_exp, n_sg / 1000, n_sg / ms_exp, n_sg / (ms_moves + ms_exp), same ? "same positions" : "POSITIONS DIFFER");
+            }
+        }
         void *d1 = nullptr, *d2 = nullptr, *dsc = nullptr, *dlen = nullptr, *dtb = nullptr;
         if (hipMalloc(&d1, n_sg * kLen) != hipSuccess || hipMalloc(&d2, n_sg * kLen) != hipSuccess ||
             hipMalloc(&dsc, n_sg * 4) != hipSuccess || hipMalloc(&dlen, n_sg * 4) != hipSuccess ||

@@ -97,6 +97,9 @@ def load():
     lib.swmi_unpack.argtypes = [vp, sz, vp]
     lib.swmi_semiglobal_xdrop.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.swmi_semiglobal_xdrop_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    lib.swmi_semiglobal_xdrop_moves.argtypes = [vp, vp, sz, vp, vp, vp]
+    lib.swmi_semiglobal_xdrop_moves_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    lib.swmi_semiglobal_expand_moves.argtypes = [vp, ctypes.c_uint32, vp, sz]
     lib.swmi_schedule_for_batch.argtypes = [sz]
     lib.swmi_semiglobal_time_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
@@ -415,6 +418,35 @@ def semiglobal_xdrop(seq1s, seq2s, cap=SG_MAX_TRACEBACK):
     _check(load().swmi_semiglobal_xdrop(a.ctypes.data, b.ctypes.data, n, scores.ctypes.data, tb.ctypes.data, cap,
                                         lengths.ctypes.data))
     return scores, [tb[k, : min(int(lengths[k]), cap)].copy() for k in range(n)], lengths
+
+
+SG_MOVE_WORDS = 1025
+
+
+def semiglobal_xdrop_moves(seq1s, seq2s):
+    """The same alignments with the traceback as MOVES (swmi_semiglobal_xdrop_moves): (scores[n], moves[n, SG_MOVE_WORDS] uint64,
+    lengths[n]); move t of alignment k = (moves[k, t // 32] >> 2 * (t % 32)) & 3 in walking order (3 diagonal, 2 up, 1 left)."""
+    a = np.ascontiguousarray(seq1s, dtype=np.uint8).reshape(-1, SG_LEN)
+    b = np.ascontiguousarray(seq2s, dtype=np.uint8).reshape(-1, SG_LEN)
+    n = a.shape[0]
+    scores = np.zeros(n, np.int32)
+    lengths = np.zeros(n, np.uint32)
+    moves = np.zeros((n, SG_MOVE_WORDS), np.uint64)
+    _check(load().swmi_semiglobal_xdrop_moves(a.ctypes.data, b.ctypes.data, n, scores.ctypes.data, moves.ctypes.data, lengths.ctypes.data))
+    return scores, moves, lengths
+
+
+def semiglobal_expand_moves(moves_row, length, cap=None):
+    """One alignment's moves -> the reference's (length, 2) traceback array, on the host (swmi_semiglobal_expand_moves)."""
+    row = np.ascontiguousarray(moves_row, dtype=np.uint64)
+    cap = int(length) if cap is None else int(cap)
+    tb = np.zeros((min(int(length), cap), 2), np.int32)
+    _check(load().swmi_semiglobal_expand_moves(row.ctypes.data, int(length), tb.ctypes.data, cap))
+    return tb
+
+
+def semiglobal_xdrop_moves_device(d_seq1s, d_seq2s, n, d_scores, d_moves, d_lengths, stream=0):
+    _check(load().swmi_semiglobal_xdrop_moves_device(d_seq1s, d_seq2s, n, d_scores, d_moves, d_lengths, stream))
 
 
 def semiglobal_xdrop_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_lengths, stream=0):

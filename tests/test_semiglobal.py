@@ -203,3 +203,120 @@ def test_gpu_semiglobal_mapping_choice_and_argument_check(gpu, swmi_mod):
         assert swmi_mod.semiglobal_kernels_for_batch(5)[0] == "sg_forward_lane_kernel<3>"
     finally:
         swmi_mod.semiglobal_set_mapping(-1)
+
+
+def _fixture_moves_words(f, k):
+    """Fixture F6 stores alignment k's steps in ASCENDING order as 1 diagonal / 2 up / 3 left; the library's move words hold them in
+    walking order (last step first) as 3 diagonal / 2 up / 1 left, 32 per 64-bit word."""
+    steps = f["moves"][f["move_offsets"][k]: f["move_offsets"][k + 1]][::-1]
+    code = {1: 3, 2: 2, 3: 1}
+    words = np.zeros(1025, np.uint64)
+    for t, m in enumerate(steps):
+        words[t >> 5] |= np.uint64(code[int(m)]) << np.uint64(2 * (t & 31))
+    return words
+
+
+def test_expand_moves_on_the_host_reproduces_the_reference_tracebacks(swmi_mod, golden):
+    """swmi_semiglobal_expand_moves (no device): move words built from the reference's own paths (fixture F6) come back as the
+    reference's traceback vectors, position by position; `cap` cuts the list, a length outside [1, 32769] is refused."""
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    for k in range(len(paths)):
+        words = _fixture_moves_words(f, k)
+        tb = swmi_mod.semiglobal_expand_moves(words, int(f["lengths"][k]))
+        assert np.array_equal(tb, paths[k]), k
+        assert np.array_equal(swmi_mod.semiglobal_expand_moves(words, int(f["lengths"][k]), cap=100), paths[k][:100])
+    assert np.array_equal(swmi_mod.semiglobal_expand_moves(np.zeros(1025, np.uint64), 1), np.zeros((1, 2), np.int32))
+    for bad in (0, 32770):
+        with pytest.raises(swmi_mod.SwmiError):
+            swmi_mod.semiglobal_expand_moves(np.zeros(1025, np.uint64), bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", [-1, 4, 2, 1])
+def test_gpu_semiglobal_moves_entry_matches_reference_fixtures(gpu, golden, sg_kernels, sweep):
+    """swmi_semiglobal_xdrop_moves: the traceback as 2-bit moves (8 KB per alignment over PCIe instead of 262 KB of positions).
+    Scores, lengths, the move words themselves and their host-side expansion against fixture F6 (the reference's results)."""
+    sg_kernels(sweep)
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    scores, moves, lengths = gpu.semiglobal_xdrop_moves(f["seq1"], f["seq2"])
+    assert np.array_equal(scores, f["scores"])
+    assert np.array_equal(lengths.astype(np.int64), f["lengths"].astype(np.int64))
+    for k in range(len(paths)):
+        want = _fixture_moves_words(f, k)
+        used = (int(lengths[k]) - 1 + 31) // 32
+        assert np.array_equal(moves[k, :used], want[:used]), k          # (words past the last step are unspecified)
+        assert np.array_equal(gpu.semiglobal_expand_moves(moves[k], int(lengths[k])), paths[k]), k
+        ups, lefts = int(paths[k][-1][0]), int(paths[k][-1][1])         # the best cell = (steps with bit 1, steps with bit 0)
+        codes = [(int(moves[k, t >> 5]) >> (2 * (t & 31))) & 3 for t in range(int(lengths[k]) - 1)]
+        assert sum(c >> 1 for c in codes) == ups and sum(c & 1 for c in codes) == lefts
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_moves_device_entry_and_chunked_host_entry(gpu, oracle):
+    """The device-resident form of the moves entry, and the host form over more than one chunk of 8192 alignments."""
+    import torch
+    rng = np.random.default_rng(16)
+    base_a = rng.integers(0, 4, (5, 16384), dtype=np.uint8)
+    base_b = base_a.copy()
+    for k in range(5):
+        idx = rng.integers(0, 16384, 300 * (k + 1))
+        base_b[k, idx] = rng.integers(0, 4, idx.shape, dtype=np.uint8)
+    base_b[4, 5000:] = np.roll(base_b[4], -17)[5000:]
+    want = [oracle.semiglobal(base_a[k], base_b[k]) for k in range(5)]
+    n = 8192 + 77
+    pick = rng.integers(0, 5, n)
+    a, b = base_a[pick], base_b[pick]
+    scores, moves, lengths = gpu.semiglobal_xdrop_moves(a, b)
+    assert np.array_equal(scores, np.array([want[k][0] for k in pick], np.int32))
+    assert np.array_equal(lengths, np.array([len(want[k][1]) for k in pick], np.uint32))
+    for j in list(range(0, n, 211)) + [8191, 8192, n - 1]:
+        assert np.array_equal(gpu.semiglobal_expand_moves(moves[j], int(lengths[j])), want[pick[j]][1]), j
+    m = 130
+    dev = torch.device("cuda", 0)
+    d1, d2 = torch.from_numpy(a[:m].copy()).to(dev), torch.from_numpy(b[:m].copy()).to(dev)
+    d_scores = torch.empty(m, dtype=torch.int32, device=dev)
+    d_len = torch.empty(m, dtype=torch.int32, device=dev)
+    d_moves = torch.zeros(m * gpu.SG_MOVE_WORDS, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream()
+    gpu.semiglobal_xdrop_moves_device(d1.data_ptr(), d2.data_ptr(), m, d_scores.data_ptr(), d_moves.data_ptr(), d_len.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_scores.cpu().numpy(), scores[:m])
+    got = d_moves.cpu().numpy().view(np.uint64).reshape(m, gpu.SG_MOVE_WORDS)
+    for j in range(0, m, 13):
+        used = (int(lengths[j]) - 1 + 31) // 32
+        assert np.array_equal(got[j, :used], moves[j, :used]), j
+
+
+@pytest.mark.gpu
+def test_cpp_compat_semiglobal_overloads(gpu, golden, tmp_path):
+    """include/swmi_compat.hpp's SemiGlobal_AdaptiveBanded_XDrop_mi355x / swmi::SemiGlobal_mi355x_batch from a plain C++ program
+    (g++, no HIP headers): scores, lengths, end cells and a checksum of every traceback against fixture F6."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import PKG, ROOT
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    n = len(paths)
+    raw = np.stack([f["seq1"], f["seq2"]], axis=1).astype(np.uint8)             # n x 2 x 16384
+    data = tmp_path / "alignments.bin"
+    raw.tofile(str(data))
+    exe = str(tmp_path / "compat_semiglobal")
+    lib = os.path.join(PKG, "lib")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "native", "compat_semiglobal.cpp"), "-o", exe, "-L", lib, "-lswmi", "-lpthread",
+                            "-Wl,-rpath," + lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    run = subprocess.run([exe, str(data)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert run.returncode == 0, run.stderr
+    rows = [tuple(map(int, line.split())) for line in run.stdout.strip().splitlines()]
+    assert len(rows) == n
+    for k, (score, length, ei, ej, checksum) in enumerate(rows):
+        want = 0
+        for i, j in paths[k]:
+            want = (want * 1000003 + int(i) * 32771 + int(j)) % (1 << 64)
+        assert (score, length, ei, ej, checksum) == (int(f["scores"][k]), len(paths[k]), int(paths[k][-1][0]), int(paths[k][-1][1]), want), k
