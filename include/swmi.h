@@ -260,7 +260,7 @@ SWMI_API int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq
  * reference's list = steps + 1; words past the last step are unspecified.  swmi_semiglobal_expand_moves() turns one
  * alignment's moves into the reference's (i, j) list on the host (no device; `cap` positions at most) -- the C++ overload of
  * swmi_compat.hpp does that on several threads.  The best cell is (number of steps with bit 1, number with bit 0). */
-#define SWMI_SG_MOVE_WORDS 1025
+#define SWMI_SG_MOVE_WORDS 1040      /* 1025 words hold the longest path; rows are padded to whole 128-byte lines */
 SWMI_API int swmi_semiglobal_xdrop_moves(const uint8_t *seq1s, const uint8_t *seq2s, size_t n, int32_t *scores,
                                          uint64_t *moves, uint32_t *lengths);
 SWMI_API int swmi_semiglobal_xdrop_moves_device(const void *d_seq1s, const void *d_seq2s, size_t n, void *d_scores,

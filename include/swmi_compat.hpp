@@ -48,7 +48,7 @@ inline std::vector<std::pair<int, int>> expand_moves(const uint64_t *moves, uint
 // The reference's SpeedtestSemiGlobal loop (source.cpp:2818-2856) over arrays of pairs: result[k] ==
 // SemiGlobal_AdaptiveBanded_XDrop_111_32_70(seq1s[k], seq2s[k]).  The GPU returns 2 bits per traceback step (8 KB per
 // alignment over PCIe instead of the 262 KB its positions take); the positions are rebuilt here, on `threads` host threads
-// (0 = as many as the machine reports, at most 64).
+// (0 = as many as the machine reports, at most 64), one slice of 16384 alignments while the GPU works on the next.
 inline std::vector<std::pair<int, std::vector<std::pair<int, int>>>> SemiGlobal_mi355x_batch(
     const std::vector<std::array<uint8_t, 16384>> &seq1s, const std::vector<std::array<uint8_t, 16384>> &seq2s, unsigned threads = 0)
 {
@@ -57,21 +57,34 @@ inline std::vector<std::pair<int, std::vector<std::pair<int, int>>>> SemiGlobal_
     const size_t n = seq1s.size();
     std::vector<std::pair<int, std::vector<std::pair<int, int>>>> out(n);
     if (n == 0) return out;
+    if (threads == 0) threads = std::thread::hardware_concurrency();
+    threads = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    constexpr size_t kSlice = 16384;                   // two of the library's internal chunks: its copies and kernels overlap inside a call
     std::vector<int32_t> scores(n);
     std::vector<uint32_t> lengths(n);
     std::vector<uint64_t> moves(n * size_t(SWMI_SG_MOVE_WORDS));
-    if (swmi_semiglobal_xdrop_moves(seq1s[0].data(), seq2s[0].data(), n, scores.data(), moves.data(), lengths.data()) != SWMI_OK)
-        throw std::runtime_error(std::string("swmi_semiglobal_xdrop_moves: ") + swmi_last_error());
-    if (threads == 0) threads = std::thread::hardware_concurrency();
-    threads = threads < 1 ? 1 : threads > 64 ? 64 : threads;
-    if (threads > n) threads = unsigned(n);
-    auto work = [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) out[k] = {scores[k], expand_moves(moves.data() + k * size_t(SWMI_SG_MOVE_WORDS), lengths[k])};
+    std::vector<std::thread> pool;                     // the expanders of the slice before the one the GPU works on
+    std::string failed;
+    auto join_all = [&] {
+        for (auto &th : pool) th.join();
+        pool.clear();
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work, n * t / threads, n * (t + 1) / threads);
-    work(0, n / threads);
-    for (auto &th : pool) th.join();
+    for (size_t off = 0; off < n && failed.empty(); off += kSlice) {
+        const size_t m = n - off < kSlice ? n - off : kSlice;
+        if (swmi_semiglobal_xdrop_moves(seq1s[off].data(), seq2s[off].data(), m, scores.data() + off,
+                                        moves.data() + off * size_t(SWMI_SG_MOVE_WORDS), lengths.data() + off) != SWMI_OK)
+            failed = swmi_last_error();
+        join_all();
+        if (!failed.empty()) break;
+        const unsigned use = threads > m ? unsigned(m) : threads;
+        for (unsigned t = 0; t < use; ++t)
+            pool.emplace_back([&, off, m, t, use] {
+                for (size_t k = off + m * t / use; k < off + m * (t + 1) / use; ++k)
+                    out[k] = {scores[k], expand_moves(moves.data() + k * size_t(SWMI_SG_MOVE_WORDS), lengths[k])};
+            });
+    }
+    join_all();
+    if (!failed.empty()) throw std::runtime_error("swmi_semiglobal_xdrop_moves: " + failed);
     return out;
 }
 

@@ -736,7 +736,8 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
 //
 // sg_expand_kernel: one wavefront per alignment turns the moves (the tags) into the (i, j) list of source.cpp:1951-1975, in
 // ascending order from (0,0) (see the kernel).
-constexpr int kMoveWords = kMaxRound / 32 + 1;           // uint64 words of 32 moves per alignment
+constexpr int kMoveWords = (kMaxRound / 32 + 1 + 15) & ~15;   // uint64 words of 32 moves per alignment (1025), padded to whole
+                                                         // 128-byte lines (1040): a walk's words leave sixteen at a time, one line
 constexpr int kWinQuads = kCodeWindow / 2;               // uint4 = two rounds; 8 per line
 constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uint4 (padded)
 
@@ -748,94 +749,166 @@ constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uin
 // depend on the walk (it is computed off the chain), and what is carried from round to round is -2 y and -round:
 //     active = (rho - r - 1) >> 31;  tag = (record >> (2 (31 + rho - rights) - 2 y)) & 3 & active;  -2y += tag & 2;  -r += popcount(tag)
 // 15 instructions per round, no branch, no memory access.  The moves leave as the raw tags (3 diag, 2 up, 1 left).
-__global__ void __launch_bounds__(64)
+//
+// TWO WAVEFRONTS per 64 walks (round 4): a LOADER that only moves records -- global memory to registers two windows ahead, registers
+// to one of two LDS slots -- and a DECODER that only walks, one workgroup barrier per window between them.  With both jobs in
+// one wavefront (round 3) the kernel took the SUM of its halves: 4.15 ms at 65536 walks, of which the decoding alone (records
+// served from the cache) is 1.61 ms and the fetch alone, as a bare streaming kernel of the same shape, 2.75 ms
+// (profiles/r04_sg_walk_parts.txt, profiles/r04_hbm_stream.txt) -- a lone wavefront on a SIMD that waits for memory computes
+// nothing, and one that computes issues no loads.  Split, the loader's waits and the decoder's chain overlap -- PROVIDED the
+// decoder issues no vector memory operation of its own inside the loop: its occasional loads (the band's move bits, once
+// per block) and stores (a finished word of 32 moves, every two or three windows) queue up behind the loader's 16 KB of
+// requests in the CU's memory pipeline, and the wavefront stalls at the ISSUE of each (3.94 ms with them, 3.03 ms without:
+// profiles/r04_sg_walk_parts.txt, build 3).  So both go through the loader and LDS: the loader fetches the move bits of the
+// block below and leaves them in LDS before the barrier at which the decoder steps down; the decoder puts every finished
+// word of 32 moves into a ring of 32 words per walk in LDS, and the loader writes a walk's words out SIXTEEN at a time, one
+// whole 128-byte line (a 64-byte piece of a line costs a read of the whole line on top of the write).  (Written one by one -- 8 bytes per walk, 8 KB apart, 64 separate memory transactions per store
+// instruction, 67 M of them per 65536 walks -- the stores cost ~1 ms wherever they were issued: moved from the decoder to the
+// loader as they were, the kernel went from 3.94 to 4.28 ms.)
+// A/B builds of the walk only (make ab_walk, tools/experiments/sg_walk_parts.sh; never shipped): SG_WALK_EXP = 1 reads window 0
+// every time (the records come out of the cache: what the decoding alone costs).
+#ifndef SG_WALK_EXP
+#define SG_WALK_EXP 0
+#endif
+__global__ void __launch_bounds__(128)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
                     int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
 {
     constexpr int WALKS = 64;
-    constexpr int kPieces = WALKS / 8;                    // 16-byte pieces per lane and window: 64 lines of 128 bytes over 64 lanes
-    __shared__ uint4 line_codes[WALKS * kLinePitch];      // [walk][two rounds], padded
-    const int lane = threadIdx.x;
+    constexpr int kRing = 32;                             // move words per walk in LDS: the loader flushes 16 as soon as it sees 16
+    __shared__ uint4 line_codes[2][WALKS * kLinePitch];   // two slots of [walk][two rounds], padded
+    __shared__ uint32_t dirs_lds[2][WALKS];               // move bits of block b for every walk, slot b & 1 (loader -> decoder)
+    __shared__ unsigned long long ring_lds[WALKS][kRing + 1];   // finished move words of every walk, word i in slot i % kRing (row padded)
+    __shared__ uint32_t count_lds[WALKS];                 // words finished so far per walk (decoder -> loader, once per trip)
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;                // (wave-uniform) wavefront 1 loads, wavefront 0 walks
     const uint32_t a_first = blockIdx.x * WALKS;
-    const uint32_t a0 = a_first + threadIdx.x;
+    const uint32_t a0 = a_first + lane;
     const bool real = a0 < n;
     const uint32_t a = real ? a0 : n - 1;                 // tail lanes shadow the last alignment and store nothing
-    const uint4 *all_codes = reinterpret_cast<const uint4 *>(codes);
-    const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
-    unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
-    int4 sum = summary[a];
-    int y = sum.w + 31 - sum.z;                           // .w = row of the band's top cell in the best round
-    int x = sum.y - y;                                    // y + x = the round of the best cell
-    // first window of the wavefront = the highest one any of its walks starts in
+    const int4 sum = summary[a];
+    // first window of the workgroup = the highest one any of its walks starts in; both wavefronts derive it the same way
     int wmax = sum.y / kCodeWindow;
     wmax = row16_max(wmax);
     wmax = max(max(__builtin_amdgcn_readlane(wmax, 0), __builtin_amdgcn_readlane(wmax, 16)),
                max(__builtin_amdgcn_readlane(wmax, 32), __builtin_amdgcn_readlane(wmax, 48)));
+    // The windows are taken block by block of 32 rounds -- upper window 2 blk + 1, lower window 2 blk -- from w_top = wmax | 1
+    // down to 0: a workgroup whose first window is a LOWER one starts one window higher; no walk stands in a round of that
+    // window, so it passes without a step (its records are fetched but never looked at; past the last window of the buffer the
+    // last one is fetched again).  Window w_top - i is processed in trip i and lives in LDS slot i & 1.
+    const int w_top = wmax | 1;
+    // One barrier per window: before it the loader has put window (trip + 1) into the other slot and the decoder has finished
+    // reading this trip's slot.  Only LDS traffic has to be visible across it (the fence names the local address space: a
+    // plain workgroup fence would also wait for the loader's global loads, i.e. drain its prefetch).
+    auto window_barrier = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
 
+    if (loader) {
+        // The WALKS lines of a window (one per walk) lie side by side in memory: the wavefront fetches them COOPERATIVELY, 1 KB
+        // per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 8, quarter p % 8 -- and hands them to the
+        // walks through LDS.  (A ragged last block repeats the batch's last line.)
+        const uint4 *all_codes = reinterpret_cast<const uint4 *>(codes);
+        static_assert(kWinQuads == 8, "eight pieces per window");
+        auto piece_offset = [&](int i) -> uint32_t {      // uint4 offset of this lane's piece i inside a window's lines
+            const uint32_t w_a = a_first + (uint32_t)((i * 64 + lane) >> 3);
+            return (w_a < n ? w_a : n - 1) * kWinQuads + (uint32_t)(lane & 7);
+        };
+        const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3), o4 = piece_offset(4),
+                       o5 = piece_offset(5), o6 = piece_offset(6), o7 = piece_offset(7);
+        uint4 *my_slot = &line_codes[0][(lane >> 3) * kLinePitch + (lane & 7)];      // piece i goes 8 walks (rows) further down
+        constexpr int kSlot = WALKS * kLinePitch;                                    // uint4 per LDS slot
+        // (the eight pieces of a window are sixteen plain variables and two macros: arrays or structs handed to lambdas by
+        // reference stayed in scratch memory in round 3)
+#define SG_LOAD_WINDOW(w, P)                                                                                          \
+        do {                                                                                                          \
+            const int w_ = SG_WALK_EXP == 1 ? 0 : (w) > 0 ? ((w) < kCodeWindows ? (w) : kCodeWindows - 1) : 0;       \
+            const uint4 *base_ = all_codes + (size_t)w_ * n * kWinQuads;                                              \
+            P##0 = base_[o0]; P##1 = base_[o1]; P##2 = base_[o2]; P##3 = base_[o3];                                   \
+            P##4 = base_[o4]; P##5 = base_[o5]; P##6 = base_[o6]; P##7 = base_[o7];                                   \
+        } while (0)
+#define SG_TO_LDS(P, slot)                                                                                            \
+        do {                                                                                                          \
+            uint4 *dst_ = my_slot + (slot) * kSlot;                                                                   \
+            dst_[0 * 8 * kLinePitch] = P##0; dst_[1 * 8 * kLinePitch] = P##1; dst_[2 * 8 * kLinePitch] = P##2;        \
+            dst_[3 * 8 * kLinePitch] = P##3; dst_[4 * 8 * kLinePitch] = P##4; dst_[5 * 8 * kLinePitch] = P##5;        \
+            dst_[6 * 8 * kLinePitch] = P##6; dst_[7 * 8 * kLinePitch] = P##7;                                         \
+        } while (0)
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4, wa4 = z4, wa5 = z4, wa6 = z4, wa7 = z4;
+        uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4, wb4 = z4, wb5 = z4, wb6 = z4, wb7 = z4;
+        const uint32_t *my_dirs = dirs + a;               // word b of walk `lane` at my_dirs[b * n]: 256 contiguous bytes per wavefront
+        unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
+        count_lds[lane] = 0u;
+        uint32_t flushed = 0;                             // words of this lane's walk already in global memory (a multiple of 16)
+        // what the decoder has finished since: out to global memory as soon as there are sixteen words, one aligned line
+        auto drain = [&]() {
+            const uint32_t have = count_lds[lane];        // (as of the last barrier)
+            if (have - flushed >= 16u) {
+                const unsigned long long *src = &ring_lds[lane][flushed % kRing];      // 0 or 16: sixteen consecutive slots
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                if (real) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const u64x2 v = {src[2 * q], src[2 * q + 1]};
+                        *reinterpret_cast<u64x2 *>(my_moves + flushed + 2 * q) = v;
+                    }
+                }
+                flushed += 16u;
+            }
+        };
+        SG_LOAD_WINDOW(w_top, wa);
+        SG_LOAD_WINDOW(w_top - 1, wb);
+        SG_TO_LDS(wa, 0);
+        window_barrier();                                 // trip 0 may start: window w_top is in slot 0
+        // trip i (window w = w_top - i in slot i & 1): request window w - 2, put window w - 1 into the other slot
+        int blk = w_top / 2;
+        for (int w = w_top;;) {                           // w is odd here: the upper window of block blk
+            const int nb = blk > 0 ? blk - 1 : 0;         // (block 0 again below block 0: never used)
+            const unsigned d_next = my_dirs[(size_t)nb * n];
+            SG_LOAD_WINDOW(w - 2, wa); drain(); SG_TO_LDS(wb, 1); window_barrier(); --w;
+            SG_LOAD_WINDOW(w - 2, wb); drain(); if (w == 0) break;
+            dirs_lds[nb & 1][lane] = d_next;              // before the barrier at which the decoder steps down into block nb
+            SG_TO_LDS(wa, 0); window_barrier(); --w;
+            --blk;
+        }
+#undef SG_LOAD_WINDOW
+#undef SG_TO_LDS
+        window_barrier();                                 // the decoder has left its last words and the final count
+        if (real) {
+            const uint32_t have = count_lds[lane];        // whatever is left, word by word: fewer than 16 + 2 per walk
+            for (uint32_t k = flushed; k < have; ++k) my_moves[k] = ring_lds[lane][k % kRing];
+        }
+        return;
+    }
+
+    // ---- the decoder ----
+    const uint32_t *my_dirs = dirs + a;                   // word w at my_dirs[w * n]: the 64 walks read 256 contiguous bytes
+    const int y = sum.w + 31 - sum.z;                     // .w = row of the band's top cell in the best round
+    const int x = sum.y - y;                              // y + x = the round of the best cell
     int nr = -(y + x), ny2 = -2 * y;                      // minus the round of the walk's cell, minus twice its row
     uint32_t steps = 0;                                   // moves made
     unsigned long long acc = 0;                           // the last (steps & 31) moves, 2 bits each
-    // The WALKS lines of a window (one per walk of this wavefront) lie side by side in memory: the wavefront fetches them
-    // COOPERATIVELY, 1 KB per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 8, quarter p % 8 -- and
-    // hands them to the walks through LDS.  (A ragged last block repeats the batch's last line.)
-    // (the eight pieces of a window are sixteen plain variables and two macros: arrays or structs handed to lambdas by
-    // reference stayed in scratch memory, 272 bytes of it, and the walk ran 35 % slower than round 2's)
-    static_assert(kWinQuads == 8, "eight pieces per window");
-    auto piece_offset = [&](int i) -> uint32_t {          // uint4 offset of this lane's piece i inside a window's lines
-        const uint32_t w_a = a_first + (uint32_t)((i * 64 + lane) >> 3);
-        return (w_a < n ? w_a : n - 1) * kWinQuads + (uint32_t)(lane & 7);
-    };
-    const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3), o4 = piece_offset(4),
-                   o5 = piece_offset(5), o6 = piece_offset(6), o7 = piece_offset(7);
-    uint4 *my_slot = &line_codes[(lane >> 3) * kLinePitch + (lane & 7)];             // piece i goes 8 walks (rows) further down
-#define SG_LOAD_WINDOW(w, P)                                                                                          \
-    do {                                                                                                              \
-        const uint4 *base_ = all_codes + (size_t)((w) > 0 ? (w) : 0) * n * kWinQuads;   /* below window 0: window 0 again */ \
-        P##0 = base_[o0]; P##1 = base_[o1];                                                                            \
-        if constexpr (kPieces > 2) { P##2 = base_[o2]; P##3 = base_[o3]; }                                            \
-        if constexpr (kPieces > 4) { P##4 = base_[o4]; P##5 = base_[o5]; P##6 = base_[o6]; P##7 = base_[o7]; }        \
-    } while (0)
-#define SG_TO_LDS(P)                                                                                                  \
-    do {                                                                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       /* the walks have read the window that is replaced */ \
-        __builtin_amdgcn_wave_barrier();                                                                              \
-        my_slot[0 * 8 * kLinePitch] = P##0; my_slot[1 * 8 * kLinePitch] = P##1;                                        \
-        if constexpr (kPieces > 2) { my_slot[2 * 8 * kLinePitch] = P##2; my_slot[3 * 8 * kLinePitch] = P##3; }        \
-        if constexpr (kPieces > 4) {                                                                                  \
-            my_slot[4 * 8 * kLinePitch] = P##4; my_slot[5 * 8 * kLinePitch] = P##5;                                    \
-            my_slot[6 * 8 * kLinePitch] = P##6; my_slot[7 * 8 * kLinePitch] = P##7;                                    \
-        }                                                                                                             \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                         \
-        __builtin_amdgcn_wave_barrier();                                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
-    } while (0)
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-    uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4, wa4 = z4, wa5 = z4, wa6 = z4, wa7 = z4;
-    uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4, wb4 = z4, wb5 = z4, wb6 = z4, wb7 = z4;
-    SG_LOAD_WINDOW(wmax, wa);
-    SG_LOAD_WINDOW(wmax - 1, wb);
     // Band row of a round r = r - (right moves up to and including r) = r - (rights_before + popcount of the block's move
     // bits up to r): no state carried from step to step, and a shorter dependency chain than an LDS lookup.
     // d_blk = move bits of the 32-round block the current window lies in; rights_before = right moves before that block,
     // known from the best round's band row when the wavefront reaches the block this walk starts in.
-    int blk = wmax / 2;                                   // two windows per block of 32 rounds
+    int blk = wmax / 2;                                   // two windows per block of 32 rounds: 2 blk + 1 (upper), 2 blk (lower)
     const int start_blk = sum.y >> 5;
     unsigned d_blk = my_dirs[(size_t)blk * n];
-    unsigned d_below = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;         // the block below, requested a block ahead
     int rights_before = 0;
     auto enter_block = [&]() {
         if (blk == start_blk) rights_before = (sum.y - sum.w) - __popc(d_blk & ((2u << (sum.y & 31)) - 1u));
     };
     enter_block();
-    SG_TO_LDS(wa);
-    const uint4 *my_line = &line_codes[lane * kLinePitch];
-    auto walk_window = [&](int w) {
+    auto walk_window = [&](int w, const bool upper, const uint4 *my_line) {   // upper: window 2 blk + 1 of its block (a constant at every call)
         uint4 rec[kWinQuads];                             // rounds 16 w + 2 j (.x, .y) and 16 w + 2 j + 1 (.z, .w)
 #pragma unroll
         for (int j = 0; j < kWinQuads; ++j) rec[j] = my_line[j];
         // the window's 16 move bits and the right moves before it
-        const bool upper = (w & 1) != 0;                  // (wave-uniform)
         const unsigned d_win = upper ? d_blk >> 16 : d_blk & 0xFFFFu;
         const int rb_win = rights_before + (upper ? (int)__popc(d_blk & 0xFFFFu) : 0);
         unsigned wm = 0;                                  // this window's moves, cnt2 / 2 of them
@@ -861,29 +934,32 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         const int fill2 = 2 * (int)(steps & 31u);
         acc |= (unsigned long long)wm << fill2;
         if (fill2 + cnt2 >= 64) {                         // (then fill2 >= 32: the shift below is 2 .. 32)
-            if (real) my_moves[steps >> 5] = acc;
+            ring_lds[lane][(steps >> 5) % kRing] = acc;   // word steps / 32 is full: into the ring (the loader writes it out)
             acc = (unsigned long long)wm >> (64 - fill2);
         }
         steps += (uint32_t)(cnt2 >> 1);
+        count_lds[lane] = steps >> 5;                     // full words so far (read by the loader after the next barrier)
     };
-    auto next_block = [&](int w) {                        // leaving window w > 0: window w - 1 comes next
-        if ((w & 1) == 0) {                               // ... and lies in the 32-round block below
-            --blk;
-            d_blk = d_below;
-            d_below = blk > 0 ? my_dirs[(size_t)(blk - 1) * n] : 0u;
-            rights_before -= (int)__popc(d_blk);
-            enter_block();
-        }
+    auto step_down = [&]() {                              // leaving a block's lower window: the loader has left the block's move bits
+        --blk;
+        d_blk = dirs_lds[blk & 1][lane];
+        rights_before -= (int)__popc(d_blk);
+        enter_block();
     };
-    // roles at the top of the loop: LDS holds window w, wb window w - 1, wa is free (two windows requested ahead)
-    for (int w = wmax;;) {
-        SG_LOAD_WINDOW(w - 2, wa); walk_window(w); if (w == 0) break; SG_TO_LDS(wb); next_block(w); --w;
-        SG_LOAD_WINDOW(w - 2, wb); walk_window(w); if (w == 0) break; SG_TO_LDS(wa); next_block(w); --w;
+    const uint4 *line0 = &line_codes[0][lane * kLinePitch], *line1 = &line_codes[1][lane * kLinePitch];
+    window_barrier();                                     // window w_top is in slot 0
+    for (int w = w_top;;) {                               // w is odd here: the upper window of block blk, in slot 0
+        walk_window(w, true, line0); window_barrier(); --w;
+        walk_window(w, false, line1); if (w == 0) break; window_barrier();
+        step_down();
+        --w;
     }
-#undef SG_LOAD_WINDOW
-#undef SG_TO_LDS
+    if (steps & 31u) {                                    // the last, partial word goes the same way
+        ring_lds[lane][(steps >> 5) % kRing] = acc;
+        count_lds[lane] = (steps >> 5) + 1u;
+    }
+    window_barrier();                                     // the loader writes out what is left in the ring
     if (real) {
-        if (steps & 31u) my_moves[steps >> 5] = acc;
         scores[a] = sum.x;
         lengths[a] = steps + 1;                           // positions = moves + 1
     }
@@ -916,13 +992,23 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
     uint4 *my_row = &stage[wv][lane * kExpPitch];
     const uint4 *my_pieces = &stage[wv][(lane >> 2) * kExpPitch + (lane & 3)];            // + j * 16 rows for store j
     unsigned carry = 0;                                   // y | x << 16 of the last position before the chunk
+    // the 64 bits of the move stream that hold the 16 this lane wants of the chunk at `base`
+    auto fetch = [&](int base) -> unsigned long long {
+        const int s = total - 1 - (base + 8 * lane) - 7;
+        const int sc = s < 0 ? 0 : s;
+        int dw = (2 * sc) >> 5;
+        dw = dw < 2 * kMoveWords - 2 ? dw : 2 * kMoveWords - 2;              // the 8-byte fetch stays inside the move words
+        return stream[dw] | ((unsigned long long)stream[dw + 1] << 32);
+    };
+    // The next chunk's moves are requested BEFORE this chunk's positions are stored: loads and stores retire in order, so a
+    // fetch issued behind the four 1 KB stores of a trip made the next trip wait for those stores as well.
+    unsigned long long w_next = fetch(-skew);
     for (int base = -skew; base < limit; base += 512) {
         const int s = total - 1 - (base + 8 * lane) - 7;  // position base + 8 lane + k takes move s + 7 - k
         // the 16 bits of the stream that start at move s (s < 0 or past the last move: those fields are masked off below)
         const int sc = s < 0 ? 0 : s;
-        int dw = (2 * sc) >> 5;
-        dw = dw < 2 * kMoveWords - 2 ? dw : 2 * kMoveWords - 2;              // the 8-byte fetch stays inside the move words
-        const unsigned long long w = stream[dw] | ((unsigned long long)stream[dw + 1] << 32);
+        const unsigned long long w = w_next;
+        w_next = fetch(base + 512);                       // (past the list: an address inside the move words, value unused)
         const int up = -2 * s < 16 ? -2 * s : 16;
         unsigned f = s >= 0 ? (unsigned)(w >> ((2 * sc) & 31)) : (unsigned)w << up;
         const int lo = -s < 0 ? 0 : (-s > 8 ? 8 : -s), hi = total - 1 - s < 0 ? 0 : (total - 1 - s > 8 ? 8 : total - 1 - s);
@@ -979,7 +1065,7 @@ sg_expand_kernel(uint32_t n, const unsigned long long *__restrict__ moves, const
 }  // namespace
 
 namespace {
-inline size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
+inline size_t round16(size_t v) { return (v + 127) & ~size_t(127); }   // (every part of the workspace starts on a 128-byte line)
 inline size_t codes_bytes(size_t n) { return round16(n * (size_t)kCodeWindows * kCodeWindow * sizeof(uint2)); }
 inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * sizeof(uint32_t)); }
 }  // namespace
@@ -1082,7 +1168,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (uint32_t)n, codes, top, summary,
+    hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, stream, (uint32_t)n, codes, top, summary,
                        moves, d_scores, d_lengths);
     if (d_tracebacks || !d_moves_out)           // (moves only: the caller expands them itself, swmi_semiglobal_expand_moves)
         hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,

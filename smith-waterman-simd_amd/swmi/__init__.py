@@ -420,7 +420,7 @@ def semiglobal_xdrop(seq1s, seq2s, cap=SG_MAX_TRACEBACK):
     return scores, [tb[k, : min(int(lengths[k]), cap)].copy() for k in range(n)], lengths
 
 
-SG_MOVE_WORDS = 1025
+SG_MOVE_WORDS = 1040
 
 
 def semiglobal_xdrop_moves(seq1s, seq2s):

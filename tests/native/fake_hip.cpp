@@ -177,6 +177,6 @@ hipError_t launch_unpack(const uint8_t *, uint8_t *, size_t, hipStream_t) { retu
 hipError_t launch_pk_max3_selftest(unsigned long long *, hipStream_t) { return hipSuccess; }
 size_t semiglobal_workspace_bytes(size_t n) { return 64 * (n + 1); }
 hipError_t launch_semiglobal(const uint8_t *, const uint8_t *, size_t, void *, int32_t *, int32_t *, size_t, uint32_t *, hipStream_t, hipEvent_t, int, SgTuning, unsigned long long *) { return hipSuccess; }
-size_t semiglobal_move_words() { return 1025; }
+size_t semiglobal_move_words() { return 1040; }
 void semiglobal_kernel_names(size_t, int, char *a, size_t an, char *b, size_t bn, SgTuning) { if (a && an) a[0] = 0; if (b && bn) b[0] = 0; }
 }  // namespace swmi

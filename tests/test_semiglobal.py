@@ -210,7 +210,7 @@ def _fixture_moves_words(f, k):
     walking order (last step first) as 3 diagonal / 2 up / 1 left, 32 per 64-bit word."""
     steps = f["moves"][f["move_offsets"][k]: f["move_offsets"][k + 1]][::-1]
     code = {1: 3, 2: 2, 3: 1}
-    words = np.zeros(1025, np.uint64)
+    words = np.zeros(1040, np.uint64)
     for t, m in enumerate(steps):
         words[t >> 5] |= np.uint64(code[int(m)]) << np.uint64(2 * (t & 31))
     return words
@@ -226,10 +226,10 @@ def test_expand_moves_on_the_host_reproduces_the_reference_tracebacks(swmi_mod, 
         tb = swmi_mod.semiglobal_expand_moves(words, int(f["lengths"][k]))
         assert np.array_equal(tb, paths[k]), k
         assert np.array_equal(swmi_mod.semiglobal_expand_moves(words, int(f["lengths"][k]), cap=100), paths[k][:100])
-    assert np.array_equal(swmi_mod.semiglobal_expand_moves(np.zeros(1025, np.uint64), 1), np.zeros((1, 2), np.int32))
+    assert np.array_equal(swmi_mod.semiglobal_expand_moves(np.zeros(1040, np.uint64), 1), np.zeros((1, 2), np.int32))
     for bad in (0, 32770):
         with pytest.raises(swmi_mod.SwmiError):
-            swmi_mod.semiglobal_expand_moves(np.zeros(1025, np.uint64), bad)
+            swmi_mod.semiglobal_expand_moves(np.zeros(1040, np.uint64), bad)
 
 
 @pytest.mark.gpu
