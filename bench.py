@@ -444,6 +444,35 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
                         "traffic on top"}})
     line["roofline"] = roof
     if not args.no_cpu_baseline:
+        # the host-buffer entries (PCIe inclusive; never `value`) on the first 16384 alignments of the batch: the traceback as
+        # the reference's (i, j) list (up to 262 KB per alignment back over the link) and as the walk's 2-bit moves (8 KB)
+        m = min(P, 16384)
+        h1, h2 = d1[:m].cpu().numpy(), d2[:m].cpu().numpy()
+        lib = swmi.load()                               # the C entries themselves, output buffers allocated (and touched) beforehand
+        h_scores, h_len = np.zeros(m, np.int32), np.zeros(m, np.uint32)
+        h_tb = np.zeros((m, cap, 2), np.int32)
+        h_moves = np.zeros((m, swmi.SG_MOVE_WORDS), np.uint64)
+        host = {"alignments": m, "stat": "second of two calls, output buffers allocated beforehand"}
+        calls = (("positions", "swmi_semiglobal_xdrop", lambda: lib.swmi_semiglobal_xdrop(
+                      h1.ctypes.data, h2.ctypes.data, m, h_scores.ctypes.data, h_tb.ctypes.data, cap, h_len.ctypes.data)),
+                 ("moves", "swmi_semiglobal_xdrop_moves", lambda: lib.swmi_semiglobal_xdrop_moves(
+                      h1.ctypes.data, h2.ctypes.data, m, h_scores.ctypes.data, h_moves.ctypes.data, h_len.ctypes.data)))
+        for label, entry, call in calls:
+            h_scores[:] = -1
+            if call() != 0:
+                raise RuntimeError(entry + ": " + swmi.last_error())
+            t1 = time.perf_counter()
+            call()
+            dt1 = time.perf_counter() - t1
+            host[label] = {"entry": entry, "ms": round(dt1 * 1e3, 2), "value": round(m / dt1, 1), "unit": "alignments/s",
+                           "scores_match_resident": bool((h_scores == scores[:m].cpu().numpy()).all())}
+        host["positions"]["rows_match_resident"] = all(
+            np.array_equal(h_tb[k, : int(h_len[k])], tb[k, : int(h_len[k])].cpu().numpy()) for k in (0, m // 2, m - 1))
+        host["moves"]["expanded_rows_match_resident"] = all(   # move rows expanded on the host against the positions the device entry wrote
+            np.array_equal(swmi.semiglobal_expand_moves(h_moves[k], int(h_len[k])), tb[k, : int(h_len[k])].cpu().numpy()) for k in (0, m // 2, m - 1))
+        del h_tb, h_moves
+        line["host_buffer_path"] = host
+        del h1, h2
         ref_path = os.path.join(ROOT, "oracle", "_ref", "libswref.so")
         sample = 64
         a = d1[:sample].cpu().numpy(); b = d2[:sample].cpu().numpy()
@@ -497,6 +526,8 @@ def row_summary(line):
         out["gpu_mismatches"] = cb["gpu_mismatches"]
         out["checked_against"] = "%s, %s" % (cb["function"], cb["sample"])
         out["cpu_one_core"] = cb["value"]
+    if line.get("host_buffer_path"):
+        out["host_buffer_path"] = line["host_buffer_path"]
     return out
 
 

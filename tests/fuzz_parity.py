@@ -100,16 +100,21 @@ while time.time() < t_end:
         b[k, cut:] = np.roll(b[k], sh)[cut:]
     swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 24, 11, 12, 13)[sg_iter % 11])
     sg_iter += 1
-    scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
+    if sg_iter % 2:                      # the entry that returns the walk's 2-bit moves, expanded on the host (round 4)
+        scores, moves, lengths = swmi.semiglobal_xdrop_moves(a, b)
+        tbs = [swmi.semiglobal_expand_moves(moves[k], int(lengths[k])) for k in range(m)]
+    else:
+        scores, tbs, lengths = swmi.semiglobal_xdrop(a, b)
     with ThreadPoolExecutor(workers) as ex:
         ok = list(ex.map(check, [(a[k], b[k], int(scores[k]), tbs[k]) for k in range(m)]))
     sg_total += m; sg_bad += m - sum(ok)
     print("... semi-global %d alignments, %d mismatches" % (sg_total, sg_bad), flush=True)
-print("semi-global fuzz vs %s: %d alignments (score + full traceback), %d mismatches" % ("reference simd_mark4" if ref else "oracle", sg_total, sg_bad), flush=True)
+print("semi-global fuzz vs %s: %d alignments (score + full traceback; positions entry and moves entry + host expansion in turn), %d mismatches" % ("reference simd_mark4" if ref else "oracle", sg_total, sg_bad), flush=True)
 
 # ---- banded affine extension vs oracle/sw_oracle.c (no reference counterpart: parity unpinned by the reference) ----
 orc.sw_oracle_banded_affine.restype = ctypes.c_int
 ba_total = ba_bad = 0
+ba_kernels = {}
 t_end = time.time() + args.ba_seconds
 while time.time() < t_end:
     length = int(rng.choice([64, 65, 100, 128, 200, 333, 512, 1000, 1024, 1500, 1792]))
@@ -120,12 +125,17 @@ while time.time() < t_end:
     for k in range(0, m, 3):             # indels: offsets up to and beyond the band
         cut = int(rng.integers(1, length)); sh = int(rng.integers(1, 80))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
-    kind = int(rng.integers(0, 3))       # any int8 matrix / match-mismatch with any gaps / the usual small gaps
-    sm = (rng.integers(-128, 128, 16) if kind == 0 else
-          np.where(np.eye(4, dtype=bool), rng.integers(0, 128), rng.integers(-128, 1)).reshape(16)).astype(np.int8)
+    kind = int(rng.integers(0, 4))       # any int8 matrix / match-mismatch with any gaps / the usual small gaps / small scores, any gaps
+    if kind == 3:                        # scores small enough for the packed kernel at every length, either sign
+        sm = rng.integers(-128 if rng.random() < 0.3 else -12, 15, 16).astype(np.int8)
+    else:
+        sm = (rng.integers(-128, 128, 16) if kind == 0 else
+              np.where(np.eye(4, dtype=bool), rng.integers(0, 128), rng.integers(-128, 1)).reshape(16)).astype(np.int8)
     go, ge = (int(rng.integers(0, 20)), int(rng.integers(0, 8))) if kind == 2 else (int(rng.integers(0, 128)), int(rng.integers(0, 128)))
+    ba_kernels[swmi.banded_affine_kernel_for(length, sm, go, ge)[0]] = ba_kernels.get(swmi.banded_affine_kernel_for(length, sm, go, ge)[0], 0) + m
     got = swmi.score_banded_affine(a, b, sm, go, ge)
     want = np.array([orc.sw_oracle_banded_affine(a[k].ctypes.data_as(vp), b[k].ctypes.data_as(vp), length, sm.ctypes.data_as(vp), go, ge)
                      for k in range(m)], np.int32)
     ba_total += m; ba_bad += int((got != want).sum())
-print("banded affine fuzz vs oracle: %d alignments, %d mismatches (11 lengths 64..1792, random matrices, open/extend 0..127 either order)" % (ba_total, ba_bad), flush=True)
+print("banded affine fuzz vs oracle: %d alignments, %d mismatches (11 lengths 64..1792, random matrices, open/extend 0..127 either order); per kernel: %s" % (
+    ba_total, ba_bad, ", ".join("%s %d" % kv for kv in sorted(ba_kernels.items()))), flush=True)
