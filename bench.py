@@ -339,7 +339,7 @@ def bench_banded(args, swmi, np, torch, local_rank, steps=None, warmup=None):
 def sg_traffic(P, kernel, code_sha):
     """HBM bytes per launch of the sweep kernel from the committed PMC passes (65536 alignments), or None; quoted only
     when the profile was taken on the same kernel code."""
-    for name in ("r03_semiglobal_pmc.json", "r02_semiglobal_pmc.json", "r01_semiglobal_pmc.json"):
+    for name in ("r04_semiglobal_pmc.json", "r03_semiglobal_pmc.json", "r02_semiglobal_pmc.json", "r01_semiglobal_pmc.json"):
         f = os.path.join(ROOT, "profiles", name)
         if P != 65536 or not os.path.exists(f):
             continue
