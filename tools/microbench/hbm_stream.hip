@@ -126,6 +126,31 @@ __global__ void __launch_bounds__(64) walk_shape_kernel(const v4u *__restrict__ 
     if (x == 0x9E3779B9u) *sink = x;
 }
 
+// The semi-global expand kernel's store shape (sg_expand_kernel): every wavefront writes its own region of `region` bytes
+// front to back, 4 KB (four 1 KB non-temporal stores) per trip; COOP = the four wavefronts of a workgroup take one region
+// together, 16 KB contiguous per trip, and the workgroup goes through its four regions one after another.
+template <bool COOP>
+__global__ void __launch_bounds__(256) expand_shape_kernel(v4u *__restrict__ dst, size_t region16 /* uint4 per region */, unsigned value)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const v4u v = {value, value + 1, value + 2, value + 3};
+    if (!COOP) {
+        v4u *out = dst + ((size_t)blockIdx.x * 4 + wv) * region16;
+        for (size_t base = 0; base + 256 <= region16; base += 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v, out + base + 64 * j + lane);
+        }
+    } else {
+        for (int r = 0; r < 4; ++r) {
+            v4u *out = dst + ((size_t)blockIdx.x * 4 + r) * region16;
+            for (size_t base = (size_t)wv * 256; base + 256 <= region16; base += 1024) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v, out + base + 64 * j + lane);
+            }
+        }
+    }
+}
+
 static double time_ms(hipStream_t st, int reps, const std::function<void()> &launch)
 {
     hipEvent_t a, b;
@@ -207,6 +232,17 @@ int main(int argc, char **argv)
         WALK_CASE(2, 32) WALK_CASE(3, 32) WALK_CASE(4, 32) WALK_CASE(8, 32)
         WALK_CASE(2, 16) WALK_CASE(4, 16) WALK_CASE(8, 16)
 #undef WALK_CASE
+    }
+    // the expand kernel's shape: regions of 128 KB (the traceback of a 16395-position path), as many as the buffer holds
+    {
+        const size_t region = 128 * 1024, regions = bytes / region & ~size_t(3);
+        const double moved = (double)regions * region;
+        printf("# expand shape: %zu regions of %zu KB = %.2f GB\n", regions, region / 1024, moved / 1e9);
+        double ms = time_ms(st, 9, [&] { hipLaunchKernelGGL((expand_shape_kernel<false>), dim3((unsigned)(regions / 4)), dim3(256), 0, st, a, region / 16, 7u); });
+        printf("%-60s %8.3f ms  %6.2f TB/s\n", "expand shape: one wavefront per region, 4 KB per trip", ms, moved / ms / 1e9);
+        ms = time_ms(st, 9, [&] { hipLaunchKernelGGL((expand_shape_kernel<true>), dim3((unsigned)(regions / 4)), dim3(256), 0, st, a, region / 16, 7u); });
+        printf("%-60s %8.3f ms  %6.2f TB/s\n", "expand shape: four wavefronts per region, 16 KB per trip", ms, moved / ms / 1e9);
+        fflush(stdout);
     }
     CHECK(hipFree(a));
     CHECK(hipFree(b));
