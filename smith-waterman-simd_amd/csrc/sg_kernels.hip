@@ -863,18 +863,16 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         SG_LOAD_WINDOW(w_top, wa);
         SG_LOAD_WINDOW(w_top - 1, wb);
         SG_TO_LDS(wa, 0);
-        SG_LOAD_WINDOW(w_top - 2, wa);
         window_barrier();                                 // trip 0 may start: window w_top is in slot 0
-        // trip i (window w = w_top - i in slot i & 1): put window w - 1 into the other slot and request window w - 3 into the
-        // registers that held it AT ONCE, before the barrier: the next request must not wait for the decoder
+        // trip i (window w = w_top - i in slot i & 1): request window w - 2, put window w - 1 into the other slot
         int blk = w_top / 2;
         for (int w = w_top;;) {                           // w is odd here: the upper window of block blk
             const int nb = blk > 0 ? blk - 1 : 0;         // (block 0 again below block 0: never used)
             const unsigned d_next = my_dirs[(size_t)nb * n];
-            drain(); SG_TO_LDS(wb, 1); SG_LOAD_WINDOW(w - 3, wb); window_barrier(); --w;
-            drain(); if (w == 0) break;
+            SG_LOAD_WINDOW(w - 2, wa); drain(); SG_TO_LDS(wb, 1); window_barrier(); --w;
+            SG_LOAD_WINDOW(w - 2, wb); drain(); if (w == 0) break;
             dirs_lds[nb & 1][lane] = d_next;              // before the barrier at which the decoder steps down into block nb
-            SG_TO_LDS(wa, 0); SG_LOAD_WINDOW(w - 3, wa); window_barrier(); --w;
+            SG_TO_LDS(wa, 0); window_barrier(); --w;
             --blk;
         }
 #undef SG_LOAD_WINDOW
