@@ -121,3 +121,29 @@ def test_sixty_four_million_pairs_checksum(gpu, resident):
         torch.cuda.synchronize()
         assert torch.equal(part, big[blk * N:(blk + 1) * N])
     assert int(big.min()) >= 30 and int(big.max()) <= 600
+
+
+def test_host_batch_above_one_production_score_group(gpu, oracle):
+    """score_host_batch's several-group branch at the PRODUCTION group size (2^24 pairs = 64 MiB of scores): one host batch of
+    2^24 + 70 001 pairs (2 x 2.15 GB of host arrays) -- every score against the same pairs scored resident in one launch, and
+    the oracle on samples at the head, either side of the group boundary and the ragged tail.  The packed entry takes the same
+    path with its own schedule."""
+    n = (1 << 24) + 70001
+    sm = match_matrix(10, -30)
+    d1 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    d2 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+    gpu.generate_pairs_device(d1.data_ptr(), d2.data_ptr(), n, 4711, 0, torch.cuda.current_stream().cuda_stream)
+    want = _score(gpu, d1, d2, sm, 15, n).cpu().numpy()
+    a = d1.cpu().numpy().reshape(n, 128)
+    b = d2.cpu().numpy().reshape(n, 128)
+    del d1, d2
+    torch.cuda.empty_cache()
+    g = gpu.host_granules(n)
+    assert sum(g) == n and (1 << 24) in np.cumsum(g)          # two groups: a granule boundary at 2^24, then the tail's own schedule
+    got = gpu.score_batch(a, b, sm, 15)
+    assert np.array_equal(got, want)
+    for lo in (0, (1 << 24) - 600, (1 << 24), n - 1200):
+        hi = min(n, lo + 1200)
+        assert np.array_equal(got[lo:hi], oracle.batch(a[lo:hi], b[lo:hi], sm, 15)), lo
+    got_packed = gpu.score_batch_packed(gpu.pack(a), gpu.pack(b), sm, 15)
+    assert np.array_equal(got_packed, want)
