@@ -232,3 +232,29 @@ def test_rccl_probe_reports_a_missing_library(swmi_mod):
     assert present.returncode == 0, present.stderr
     lines = present.stdout.strip().splitlines()
     assert lines[0] in ("0", "1") and (lines[0] == "1" or len(lines) > 1)       # this image ships librccl: normally 1
+
+
+def test_host_schedule_knobs_are_read_from_the_environment():
+    """The experiment knobs of the host-batch schedule (csrc/swmi_host.h Knobs, read once by the first call that needs them):
+    SWMI_HOST_GRANULE, SWMI_HOST_TAPER + SWMI_HOST_MIN_GRANULE, SWMI_HOST_SCHEDULE (explicit list, the last entry repeats),
+    SWMI_TEST_SCORE_GROUP.  One child process per setting: the library reads its environment once."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import swmi; "
+            "print(swmi.host_granules(1 << 20, 0)); print(swmi.host_granules(1 << 20, 1)); print(swmi.host_granules(300000, 2))" % PKG)
+
+    def run(**env):
+        clean = {k: v for k, v in os.environ.items() if not k.startswith("SWMI_")}
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(clean, **env))
+        assert r.returncode == 0, r.stderr
+        return [eval(line) for line in r.stdout.strip().splitlines()]
+    pairs, packed, ovm = run(SWMI_HOST_GRANULE="262144")
+    assert pairs == [262144] * 4 and packed == [262144] * 4 and ovm == [262144, 37856]
+    pairs, packed, ovm = run(SWMI_HOST_TAPER="50", SWMI_HOST_MIN_GRANULE="65536")
+    assert pairs == [524288, 262144, 131072, 65536, 65536] and packed == pairs and ovm == [147456, 73728, 65536, 13280]
+    pairs, packed, ovm = run(SWMI_HOST_SCHEDULE="32768,65536,131072")
+    assert pairs == [32768, 65536] + [131072] * 7 + [32768] and packed == pairs and ovm == [32768, 65536, 131072, 70624]
+    pairs, packed, ovm = run(SWMI_TEST_SCORE_GROUP="524288")                 # two groups of 512K pairs, each with its own schedule
+    assert pairs == [393216, 98304, 24576, 8192] * 2 and sum(packed) == 1 << 20 and packed[: len(packed) // 2] == packed[len(packed) // 2:]
+    pairs, packed, ovm = run(SWMI_HOST_SCHEDULE="12,nonsense")               # entries outside [1024, 1M] are ignored: the default schedule
+    assert pairs == [786432, 196608, 49152, 16384]

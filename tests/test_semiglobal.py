@@ -320,3 +320,18 @@ def test_cpp_compat_semiglobal_overloads(gpu, golden, tmp_path):
         for i, j in paths[k]:
             want = (want * 1000003 + int(i) * 32771 + int(j)) % (1 << 64)
         assert (score, length, ei, ej, checksum) == (int(f["scores"][k]), len(paths[k]), int(paths[k][-1][0]), int(paths[k][-1][1]), want), k
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_mapping_survives_a_reinit(gpu):
+    """A mapping the program chose through swmi_semiglobal_set_mapping stays across swmi_shutdown / swmi_init (like the scorer's
+    schedule); only SWMI_SG_SWEEP in the environment sets it at init (init used to reset it to automatic)."""
+    try:
+        gpu.semiglobal_set_mapping(22)
+        before = gpu.semiglobal_kernels_for_batch(1000)[0]
+        gpu.shutdown()
+        gpu.init(0)
+        assert gpu.semiglobal_kernels_for_batch(1000)[0] == before and "2, 2" in before.replace("<2,2>", "<2, 2>")
+    finally:
+        gpu.semiglobal_set_mapping(-1)
+        gpu.set_schedule(0, 0)
