@@ -936,7 +936,7 @@ def multi_gpu(args, swmi, np, torch, dist, rank, world, local_rank):
             "n1_equivalent": {"value": round(legs["no_gather"]["value"] / world, 1), "unit": "alignments/s per GPU",
                               "pairs_per_gpu": P,
                               "how": "legs.no_gather.value / n_gpus (max over ranks of the wall time, same pairs per GPU, no gather); "
-                                     "a one-GPU run of this size, `bench.py --gpus 1 --pairs %d`, measured 1 002 M/s in round 3" % P,
+                                     "the same thing as its own run: `bench.py --gpus 1 --pairs %d` (at 67 108 864 pairs that measured 1 002 M/s in round 3)" % P,
                               "scaling_efficiency_from_it": round(head["value"] / legs["no_gather"]["value"], 4)},
             "legs": legs, "roofline": roof, "checksum": checksum, "ranks_agree_on_gathered_scores": ranks_agree,
             "gpu_scores_checked": checked, "gpu_mismatches": mism,
