@@ -104,7 +104,7 @@ SWMI_API int swmi_score_pair(const uint8_t seq1[SWMI_SEQ_LEN], const uint8_t seq
 /* The reference's 1M-call loop (source.cpp:3074-3082: `for 1,000,000: score = simd4(a,b,sm,gap)`)
  * as ONE call: pair k is the 128 bytes at seq1s + 128*k and seq2s + 128*k (the per-pair
  * layout of std::array<uint8_t,128>, concatenated).  Host buffers (pageable or pinned).  The PCIe link bounds this entry
- * (256 B per pair in, against ~1 ns of kernel time per pair), so the batch goes through the GPU in GRANULES on three device
+ * (256 B per pair in, against ~1 ns of kernel time per pair), so the batch goes through the GPU in GRANULES on a few device
  * buffer sets with a stream each: granule k's kernel runs while granule k+1 is being copied in, and the granules TAPER by the
  * ratio of kernel time to copy time per pair, so that no kernel is still running when the next granule has landed and
  * almost nothing is left to compute when the last copy ends: at 256 B per pair each granule is three quarters of what is
@@ -154,7 +154,10 @@ SWMI_API int swmi_score_one_vs_many_device(const void *d_seq1s, size_t n_seq1, c
 
 /* 2-bit packed inputs in the reference's own wire format (unpack(), source.cpp:1580-1583:
  * base k of byte i = (src[i] >> 2k) & 3): pair k is the 32 bytes at seq1s_packed + 32*k.
- * The kernel unpacks on the fly (no unpacked copy in HBM).  Host buffers. */
+ * The kernel unpacks on the fly (no unpacked copy in HBM).  Host buffers.  64 B per pair over the link: copy and kernel
+ * take the same time, so this entry runs near-equal granules and issues them from TWO host threads -- the caller's and a
+ * persistent helper the context creates on first use -- so that one copy command's DMA runs while the other thread
+ * prepares the next (SWMI_HOST_THREADS=1 in the environment keeps everything on the calling thread). */
 SWMI_API int swmi_score_batch_packed(const uint8_t *seq1s_packed, const uint8_t *seq2s_packed, size_t n,
                                      const int8_t score_matrix[16], int8_t gap_penalty, int32_t *scores);
 SWMI_API int swmi_score_batch_packed_device(const void *d_seq1s_packed, const void *d_seq2s_packed, size_t n,
