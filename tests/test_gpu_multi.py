@@ -178,6 +178,54 @@ def test_two_threads_through_the_c_abi(gpu, oracle):
     assert not errors, errors
 
 
+def test_three_threads_through_the_three_host_entries(gpu, oracle):
+    """Round 4's host pipeline keeps a second issuing thread inside the context (the packed entry): three caller threads drive
+    the pairs, packed and one-vs-many entries at once, at sizes on both sides of the "more than one granule" switch, while a
+    fourth keeps changing the schedule -- calls on one context serialise, every result equals the oracle."""
+    sm = match_matrix(10, -30)
+    sizes = (300000, 70000, 40000, 1 << 20)
+    a, b = oracle.generate(max(sizes), 321, 0)
+    want = oracle.batch(a, b, sm, 15)
+    want_ovm = oracle.batch(a[:300000], np.broadcast_to(b[0], (300000, 128)).copy(), sm, 15)
+    pa, pb = gpu.pack(a), gpu.pack(b)
+    errors = []
+    stop = threading.Event()
+
+    def flipper():
+        k = 0
+        while not stop.is_set():
+            gpu.set_schedule((0, 4, 8, 16)[k % 4], 0)
+            k += 1
+
+    def worker(kind):
+        try:
+            for it in range(6):
+                n = sizes[(it + kind) % len(sizes)]
+                if kind == 0:
+                    got, ref = gpu.score_batch(a[:n], b[:n], sm, 15), want[:n]
+                elif kind == 1:
+                    got, ref = gpu.score_batch_packed(pa[:n], pb[:n], sm, 15), want[:n]
+                else:
+                    n = min(n, 300000)
+                    got, ref = gpu.score_one_vs_many(a[:n], b[0], sm, 15), want_ovm[:n]
+                if not np.array_equal(got, ref):
+                    errors.append("entry %d iteration %d n %d: %d mismatches" % (kind, it, n, int((got != ref).sum())))
+        except Exception as e:      # noqa: BLE001
+            errors.append("entry %d: %r" % (kind, e))
+
+    f = threading.Thread(target=flipper)
+    ws = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    f.start()
+    for w in ws:
+        w.start()
+    for w in ws:
+        w.join()
+    stop.set()
+    f.join()
+    gpu.set_schedule(0, 0)
+    assert not errors, errors
+
+
 def test_semiglobal_on_two_streams_in_flight(gpu, oracle, golden):
     """Per-(GPU, stream) workspaces: two semi-global calls on different streams, issued back to back from two threads,
     neither waiting for the other."""
