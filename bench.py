@@ -443,6 +443,34 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
                 "note": "sequences in + (i, j) pairs out; the predecessor records between the two kernels are implementation "
                         "traffic on top"}})
     line["roofline"] = roof
+    # Two calls in flight on two streams (the library keeps a workspace per stream: tests/test_gpu_multi.py): the second
+    # call's sweep shares the SIMDs with the first one's -- two wavefronts per SIMD issue 2 instructions per ~4.5 cycles where
+    # one issues 1 per ~5 -- and the tracebacks run under the other call's sweep.  Same per-call batch, same results; a
+    # separate figure, never the row's `value` (which is one call at a time).
+    if P * 2 * (2 * L + cap * 8 + 16) < 200e9:
+        s2 = torch.cuda.Stream()
+        d1b, d2b = d1.clone(), d2.clone()
+        scores_b, lengths_b = torch.empty_like(scores), torch.empty_like(lengths)
+        tb_b = torch.empty_like(tb)
+        torch.cuda.synchronize()
+
+        def launch_pair():
+            swmi.semiglobal_xdrop_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), stream.cuda_stream)
+            swmi.semiglobal_xdrop_device(d1b.data_ptr(), d2b.data_ptr(), P, scores_b.data_ptr(), tb_b.data_ptr(), cap, lengths_b.data_ptr(), s2.cuda_stream)
+        launch_pair()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(max(1, steps // 2)):
+            launch_pair()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        line["two_calls_in_flight"] = {"value": round(2 * P * max(1, steps // 2) / dt2, 1), "unit": "alignments/s",
+                                       "ms_per_pair_of_calls": round(dt2 * 1e3 / max(1, steps // 2), 3),
+                                       "same_results_on_both_streams": bool(torch.equal(scores, scores_b) and torch.equal(lengths, lengths_b) and
+                                                                             torch.equal(tb[:: max(1, P // 256), :2048], tb_b[:: max(1, P // 256), :2048])),
+                                       "note": "two calls of %d alignments on two streams at once; not the row's value" % P}
+        del d1b, d2b, scores_b, lengths_b, tb_b, s2
+        torch.cuda.empty_cache()
     if not args.no_cpu_baseline:
         # the host-buffer entries (PCIe inclusive; never `value`) on the first 16384 alignments of the batch: the traceback as
         # the reference's (i, j) list (up to 262 KB per alignment back over the link) and as the walk's 2-bit moves (8 KB)
@@ -528,6 +556,8 @@ def row_summary(line):
         out["cpu_one_core"] = cb["value"]
     if line.get("host_buffer_path"):
         out["host_buffer_path"] = line["host_buffer_path"]
+    if line.get("two_calls_in_flight"):
+        out["two_calls_in_flight"] = line["two_calls_in_flight"]
     return out
 
 
