@@ -311,9 +311,13 @@ namespace {
 struct Granule { size_t off, m; };                   // inside its group
 
 // issue granules first, first + step, ... of `list` (one issuing thread's share); slots[] = this thread's buffer sets
+// early: granules with an index below it belong to the part of the group whose scores go back to the host while the last
+// granules still run (0 = none); behind every such granule the slot's "early" event is recorded again, so that it ends up
+// behind the slot's last early kernel, and early_done is set once this thread has issued its last early granule
 hipError_t issue_granules(Context &ctx, const std::vector<Granule> &list, size_t first, size_t step, Slot *const *slots, int n_slots,
                           const uint8_t *s1, const uint8_t *s2, size_t group, size_t in_stride, const int8_t *sm, int gap,
-                          int32_t *out, bool packed, bool one_vs_many, bool serial, bool *slot_used)
+                          int32_t *out, bool packed, bool one_vs_many, bool serial, bool *slot_used, size_t early = 0,
+                          bool *slot_early_used = nullptr, std::atomic<bool> *early_done = nullptr)
 {
     hipError_t e = hipSuccess;
     size_t j = 0;
@@ -332,7 +336,13 @@ hipError_t issue_granules(Context &ctx, const std::vector<Granule> &list, size_t
         if (e == hipSuccess && serial)
             e = hipMemcpyAsync(out + at, ctx.d_scores_all + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
         slot_used[which] = true;
+        if (i < early && e == hipSuccess) {
+            e = hipEventRecord(ctx.slot_early[&s - ctx.slots], s.stream);
+            slot_early_used[which] = true;
+        }
+        if (early_done && i + step >= early) early_done->store(true, std::memory_order_release);     // no early granule of this thread follows
     }
+    if (early_done) early_done->store(true, std::memory_order_release);
     return e;
 }
 }  // namespace
@@ -448,16 +458,36 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
         }
         bool used_mine[kSlots] = {}, used_theirs[kSlots] = {};
         hipError_t e2 = hipSuccess;
+        // With two issuing threads the group's scores return in TWO copies: the early part -- everything but the last two
+        // granules -- from the helper, as soon as it has issued its share, on the context's own stream and under the last
+        // kernels; the rest from this thread behind the last kernel.  (One copy behind everything left ~80 us of link time
+        // exposed at the end of a 1M-pair packed batch.)
+        const size_t early = threads == 2 && list.size() >= 4 ? list.size() - 2 : 0;
+        const size_t early_pairs = early ? list[early].off : 0;
         if (threads == 2 && list.size() > 1) {
             const int device = ctx.device;
+            bool early_mine[kSlots] = {}, early_theirs[kSlots] = {};
+            std::atomic<bool> mine_done{false};
             ctx.copier->submit([&, device] {
                 e2 = hipSetDevice(device);                  // per host thread, like every HIP "current device"
                 if (e2 == hipSuccess)
                     e2 = issue_granules(ctx, list, 1, 2, theirs, n_theirs, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many,
-                                        serial, used_theirs);
+                                        serial, used_theirs, early, early_theirs);
+                if (e2 != hipSuccess || early == 0) return;
+                while (!mine_done.load(std::memory_order_acquire)) std::this_thread::yield();     // (its early events are recorded)
+                for (int k = 0; k < n_mine && e2 == hipSuccess; ++k)
+                    if (early_mine[k]) e2 = hipStreamWaitEvent(ctx.stream, ctx.slot_early[mine[k] - ctx.slots], 0);
+                for (int k = 0; k < n_theirs && e2 == hipSuccess; ++k)
+                    if (early_theirs[k]) e2 = hipStreamWaitEvent(ctx.stream, ctx.slot_early[theirs[k] - ctx.slots], 0);
+                if (e2 == hipSuccess)
+                    e2 = hipMemcpyAsync(out + group, ctx.d_scores_all, early_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx.stream);
+                const hipError_t es = hipStreamSynchronize(ctx.stream);     // (a pinned destination does not block the copy call)
+                if (e2 == hipSuccess) e2 = es;
             });
-            e = issue_granules(ctx, list, 0, 2, mine, n_mine, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many, serial, used_mine);
-            ctx.copier->wait();                             // (it has ISSUED its share; the streams may still be busy)
+            e = issue_granules(ctx, list, 0, 2, mine, n_mine, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many, serial, used_mine,
+                               early, early_mine, &mine_done);
+            mine_done.store(true, std::memory_order_release);       // (also after a failure: the helper must not wait for ever)
+            ctx.copier->wait();                             // (it has ISSUED its share and copied the early scores)
             if (e == hipSuccess) e = e2;
         } else {
             e = issue_granules(ctx, list, 0, 1, mine, n_mine, s1, s2, group, in_stride, sm, gap, out, packed, one_vs_many, serial, used_mine);
@@ -476,7 +506,7 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
                 if (used_mine[k]) e = hipStreamSynchronize(mine[k]->stream);
             continue;
         }
-        // the group's scores: one copy on the last granule's stream, behind every other slot's last kernel
+        // the group's (remaining) scores: one copy on the last granule's stream, behind every other slot's last kernel
         auto join = [&](Slot *s) {
             if (s == last_slot || e != hipSuccess) return;
             hipEvent_t ev = ctx.slot_done[s - ctx.slots];
@@ -488,7 +518,8 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
         for (int k = 0; k < n_theirs; ++k)
             if (used_theirs[k]) join(theirs[k]);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(out + group, ctx.d_scores_all, group_n * sizeof(int32_t), hipMemcpyDeviceToHost, last_slot->stream);
+            e = hipMemcpyAsync(out + group + early_pairs, ctx.d_scores_all + early_pairs, (group_n - early_pairs) * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, last_slot->stream);
         // the next group overwrites d_scores_all: drain this one first (only batches above the score group get here twice)
         if (e == hipSuccess && more) e = hipStreamSynchronize(last_slot->stream);
     }
@@ -564,6 +595,10 @@ void destroy_context(Context &c)
         if (ev) (void)hipEventDestroy(ev);
         ev = nullptr;
     }
+    for (auto &ev : c.slot_early) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
     for (auto &w : c.sg_workspaces)
         if (w.second.ptr) (void)hipFree(w.second.ptr);
     c.sg_workspaces.clear();
@@ -589,6 +624,7 @@ int create_context(Context &c, int index, int device)
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     for (auto &s : c.slots) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     for (auto &ev : c.slot_done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ev : c.slot_early) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.pin), kPinPairs * (2 * kSeq + sizeof(int32_t)), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(&c.pin_dev, c.pin, 0));
     c.extra_lds = knobs().extra_lds;

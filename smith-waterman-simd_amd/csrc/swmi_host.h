@@ -151,6 +151,7 @@ struct Context {
     int32_t *d_scores_all = nullptr;    // host-batch pipeline: scores of one group of granules (up to kScoreGroup pairs)
     size_t scores_all_capacity = 0;
     hipEvent_t slot_done[kSlots] = {};  // recorded behind a slot's last kernel of a group
+    hipEvent_t slot_early[kSlots] = {}; // ... behind its last kernel of the group's EARLY granules (all but the last two)
     std::unique_ptr<Worker> copier;     // second issuing thread of the host-batch pipeline, created by the first batch that uses it
     SgSet sg_sets[2];
     // Semi-global device entry: one workspace per caller stream, so that calls on different streams may be in flight at
