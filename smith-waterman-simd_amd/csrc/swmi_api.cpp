@@ -421,7 +421,8 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
     const bool balanced = per_pair * 15 <= 1024;
     const int want_threads = knobs().host_threads ? knobs().host_threads : balanced ? 2 : 1;
     const int threads = (serial || want_threads < 2 || first_count < 2) ? 1 : 2;
-    // buffer sets: three per issuing thread (a thread's copies may run two granules ahead of its kernels)
+    // buffer sets: two per thread when two threads issue (three measured slower: copies that run further ahead compete with the
+    // kernels), three for a lone thread (round 3's pipeline)
     const int per_thread = knobs().host_slots ? knobs().host_slots : threads == 2 ? 2 : 3;
     const int used_slots = threads == 2 ? 2 * per_thread : n > score_group || first_count > size_t(per_thread) ? per_thread : int(first_count);
     for (int k = 0; k < used_slots; ++k) {
