@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 namespace swmi {
@@ -81,6 +82,7 @@ void read_knobs()
             q = *end == ',' ? end + 1 : end;
         }
     }
+    k.host_trace = num("SWMI_HOST_TRACE", 0, 1, 0) != 0;
     k.host_threads = (int)num("SWMI_HOST_THREADS", 1, kHostThreads, 0);
     k.host_slots = (int)num("SWMI_HOST_SLOTS", 2, kSlots / kHostThreads, 0);
     k.score_group = (size_t)num("SWMI_TEST_SCORE_GROUP", 4096, (long long)kScoreGroup, (long long)kScoreGroup);
@@ -310,6 +312,17 @@ int ensure_scores_all(Context &ctx, size_t pairs)
 namespace {
 struct Granule { size_t off, m; };                   // inside its group
 
+// SWMI_HOST_TRACE=1 (diagnostics only): three timing events per granule -- before its copies, behind them, behind its kernel
+struct TraceRow { size_t index, pairs; int thread; hipEvent_t ev[3]; double host_issue_ms[2]; };
+std::mutex g_trace_mu;
+std::vector<TraceRow> g_trace;
+double host_now_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 // issue granules first, first + step, ... of `list` (one issuing thread's share); slots[] = this thread's buffer sets
 // early: granules with an index below it belong to the part of the group whose scores go back to the host while the last
 // granules still run (0 = none); behind every such granule the slot's "early" event is recorded again, so that it ends up
@@ -327,12 +340,26 @@ hipError_t issue_granules(Context &ctx, const std::vector<Granule> &list, size_t
         Slot &s = *slots[which];
         SmRows rows;
         const LaunchConfig cfg = make_config(ctx, sm, gap, &rows, m);      // a small tail granule runs more lanes per alignment
+        TraceRow tr{i, m, int(first), {nullptr, nullptr, nullptr}, {0, 0}};
+        const bool trace = knobs().host_trace;
+        if (trace) {
+            for (auto &ev : tr.ev) (void)hipEventCreate(&ev);
+            tr.host_issue_ms[0] = host_now_ms();
+            (void)hipEventRecord(tr.ev[0], s.stream);
+        }
         e = hipMemcpyAsync(s.d_seq1, s1 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
         if (e == hipSuccess && !one_vs_many)
             e = hipMemcpyAsync(s.d_seq2, s2 + at * in_stride, m * in_stride, hipMemcpyHostToDevice, s.stream);
+        if (trace) (void)hipEventRecord(tr.ev[1], s.stream);
         if (e == hipSuccess)
             e = one_vs_many ? swmi::launch_score_one_vs_many(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, s.stream)
                             : swmi::launch_score(cfg, s.d_seq1, s.d_seq2, ctx.d_scores_all + off, m, rows, gap, packed, s.stream);
+        if (trace) {
+            (void)hipEventRecord(tr.ev[2], s.stream);
+            tr.host_issue_ms[1] = host_now_ms();
+            std::lock_guard<std::mutex> l(g_trace_mu);
+            g_trace.push_back(tr);
+        }
         if (e == hipSuccess && serial)
             e = hipMemcpyAsync(out + at, ctx.d_scores_all + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
         slot_used[which] = true;
@@ -529,6 +556,27 @@ int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t 
             const hipError_t es = hipStreamSynchronize(ctx.slots[k].stream);      // on failure too: copies in flight use the caller's buffers
             if (e == hipSuccess) e = es;
         }
+    if (knobs().host_trace) {                           // (every stream has drained: the events are complete)
+        std::lock_guard<std::mutex> l(g_trace_mu);
+        const double t_end = host_now_ms();
+        hipEvent_t ref = nullptr;
+        double host0 = 0;
+        for (auto &r : g_trace)
+            if (r.index == 0) { ref = r.ev[0]; host0 = r.host_issue_ms[0]; }
+        fprintf(stderr, "swmi host batch, %zu pairs, %zu B per pair: granule, pairs, issuing thread | GPU: copies start .. end, kernel end | host: issue start .. end (ms)\n",
+                n, per_pair);
+        for (auto &r : g_trace) {
+            float t[3] = {0, 0, 0};
+            for (int k = 0; k < 3; ++k)
+                if (ref) (void)hipEventElapsedTime(&t[k], ref, r.ev[k]);
+            fprintf(stderr, "  %3zu %8zu  t%d | %7.3f .. %7.3f  %7.3f | %7.3f .. %7.3f\n", r.index, r.pairs, r.thread, t[0], t[1], t[2],
+                    r.host_issue_ms[0] - host0, r.host_issue_ms[1] - host0);
+        }
+        for (auto &r : g_trace)
+            for (auto &ev : r.ev) (void)hipEventDestroy(ev);
+        fprintf(stderr, "  call returns at %.3f ms\n", t_end - host0);
+        g_trace.clear();
+    }
     if (e != hipSuccess) return fail(SWMI_ERR_HIP, "host batch on GPU %d failed: %s", ctx.device, hipGetErrorString(e));
     return SWMI_OK;
 }

@@ -38,6 +38,7 @@ struct Knobs {
                                     //   the entry's bytes per pair, next_granule())
     size_t host_min_granule = 0;    // SWMI_HOST_MIN_GRANULE: smallest granule of the tapered schedule (0 = kMinGranule)
     size_t host_schedule[16] = {};      // SWMI_HOST_SCHEDULE="a,b,c,...": explicit granule sizes (the last one repeats), experiments only
+    bool host_trace = false;            // SWMI_HOST_TRACE=1: every host batch prints its copy / kernel timeline (HIP events) to stderr
     int host_slots = 0;                 // SWMI_HOST_SLOTS: buffer sets per issuing thread (2 or 3; 0 = the entry's default)
     int host_threads = 0;               // SWMI_HOST_THREADS: issuing threads (1 or 2; 0 = the entry's default): the calling thread alone issues a host batch (round 3's pipeline), for the A/B
     size_t score_group = kScoreGroup;   // SWMI_TEST_SCORE_GROUP: pairs per score copy -- test-only, so that the several-group
