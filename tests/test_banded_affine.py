@@ -165,3 +165,28 @@ def test_gpu_banded_affine_every_kernel_by_name(gpu, oracle, sm_go_ge, want_kern
         got = gpu.score_banded_affine(a, b, m, o, e)
         want = oracle.banded_affine(a, b, m, o, e)
         assert np.array_equal(got, want), (gpu.banded_affine_kernel_for(256, m, o, e), m, o, e, int((got != want).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length, mismatch, go, ge", [(1024, -3, 5, 1), (1792, -2, 0, 0), (64, -128, 127, 127), (512, -30, 1, 100), (333, -7, 90, 3)])
+def test_gpu_banded_affine_packed_kernel_at_the_edge_of_its_domain(gpu, oracle, length, mismatch, go, ge):
+    """The packed kernel keeps every 16-bit half below 0x7C00 (a finite half-precision pattern): with the LARGEST match score
+    its domain admits at this length, identical sequences reach len * match -- the highest value any half can take, on top
+    of which sit the growing bias (up to 17 x max(0, -min s)) and the hand-over floors.  One score above, the int32 cell runs."""
+    bias = max(0, -mismatch)
+    limit = (0x7C00 - 64 - 18 * bias - go - ge - 1) // length
+    top = min(127, limit)                                                      # (an int8 score; a short band leaves room to spare)
+    assert top > 0
+    sm = match_matrix(top, mismatch)
+    assert gpu.banded_affine_kernel_for(length, sm, go, ge)[0].startswith("sw_banded_affine_pk_kernel")
+    if limit < 127:
+        assert not gpu.banded_affine_kernel_for(length, match_matrix(top + 1, mismatch), go, ge)[0].startswith("sw_banded_affine_pk_kernel")
+    rng = np.random.default_rng(length + go)
+    a, b = _related(rng, 41, length, sub=0.03, indel=0.005)
+    a[0] = rng.integers(0, 4, length, dtype=np.uint8); b[0] = a[0]             # identical: the top score len * match
+    a[1] = 2; b[1] = 2                                                         # homopolymer, identical
+    b[2] = np.roll(a[2], 1)                                                    # one diagonal off
+    got = gpu.score_banded_affine(a, b, sm, go, ge)
+    want = oracle.banded_affine(a, b, sm, go, ge)
+    assert np.array_equal(got, want), (top, int((got != want).sum()), got[:4], want[:4])
+    assert got[0] == length * top and got[1] == length * top
