@@ -185,7 +185,7 @@ SmRows pack_rows(const int8_t *sm, int add);
 LaunchConfig make_config(const Context &ctx, const int8_t *sm, int gap, SmRows *rows, size_t n);
 int launch_device(Context &ctx, const void *d1, const void *d2, size_t n, const int8_t *sm, int gap, void *d_out,
                   hipStream_t st, bool packed);
-// host arrays -> scores through ctx's two slots (the body of swmi_score_batch); takes ctx.mu
+// host arrays -> scores through ctx's buffer sets (the body of swmi_score_batch and its relatives); takes ctx.mu
 int score_host_batch(Context &ctx, const uint8_t *s1, const uint8_t *s2, size_t n, const int8_t *sm, int gap,
                      int32_t *out, bool packed, bool one_vs_many);
 
