@@ -1211,7 +1211,12 @@ static int semiglobal_host(const uint8_t *seq1s, const uint8_t *seq2s, size_t n,
     std::lock_guard<std::mutex> lock(ctx->mu);
     constexpr size_t kLen = SWMI_SG_LEN;
     const size_t move_words = swmi::semiglobal_move_words();
-    const size_t chunk = n < 8192 ? n : 8192;
+    // Chunk: 8192 alignments when positions return (2.1 GB of them per chunk: the link is the bound whatever the chunk), 32768
+    // when moves return -- a sweep of 8192 alignments takes 9.7 ms, one of 32768 takes 12.6 (one alignment is 32768
+    // sequential rounds: small launches are latency bound), and with 8 KB instead of 262 KB per alignment coming back the
+    // sweeps, not the link, were what a 65536-alignment call waited for: 77 ms, eight chunks of ~9.6 ms
+    const size_t chunk_max = moves_out ? 32768 : 8192;
+    const size_t chunk = n < chunk_max ? n : chunk_max;
     using Set = SgSet;
     Set *sets = ctx->sg_sets;
     const int n_sets = n > chunk ? 2 : 1;

@@ -255,7 +255,7 @@ def test_gpu_semiglobal_moves_entry_matches_reference_fixtures(gpu, golden, sg_k
 
 @pytest.mark.gpu
 def test_gpu_semiglobal_moves_device_entry_and_chunked_host_entry(gpu, oracle):
-    """The device-resident form of the moves entry, and the host form over more than one chunk of 8192 alignments."""
+    """The device-resident form of the moves entry, and the host form over more than one chunk (32768 alignments for this entry)."""
     import torch
     rng = np.random.default_rng(16)
     base_a = rng.integers(0, 4, (5, 16384), dtype=np.uint8)
@@ -265,13 +265,13 @@ def test_gpu_semiglobal_moves_device_entry_and_chunked_host_entry(gpu, oracle):
         base_b[k, idx] = rng.integers(0, 4, idx.shape, dtype=np.uint8)
     base_b[4, 5000:] = np.roll(base_b[4], -17)[5000:]
     want = [oracle.semiglobal(base_a[k], base_b[k]) for k in range(5)]
-    n = 8192 + 77
+    n = 32768 + 77
     pick = rng.integers(0, 5, n)
     a, b = base_a[pick], base_b[pick]
     scores, moves, lengths = gpu.semiglobal_xdrop_moves(a, b)
     assert np.array_equal(scores, np.array([want[k][0] for k in pick], np.int32))
     assert np.array_equal(lengths, np.array([len(want[k][1]) for k in pick], np.uint32))
-    for j in list(range(0, n, 211)) + [8191, 8192, n - 1]:
+    for j in list(range(0, n, 811)) + [32767, 32768, n - 1]:
         assert np.array_equal(gpu.semiglobal_expand_moves(moves[j], int(lengths[j])), want[pick[j]][1]), j
     m = 130
     dev = torch.device("cuda", 0)
