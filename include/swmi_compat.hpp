@@ -48,7 +48,7 @@ inline std::vector<std::pair<int, int>> expand_moves(const uint64_t *moves, uint
 // The reference's SpeedtestSemiGlobal loop (source.cpp:2818-2856) over arrays of pairs: result[k] ==
 // SemiGlobal_AdaptiveBanded_XDrop_111_32_70(seq1s[k], seq2s[k]).  The GPU returns 2 bits per traceback step (8 KB per
 // alignment over PCIe instead of the 262 KB its positions take); the positions are rebuilt here, on `threads` host threads
-// (0 = as many as the machine reports, at most 64), one slice of 16384 alignments while the GPU works on the next.
+// (0 = as many as the machine reports, at most 64), one slice of 65536 alignments while the GPU works on the next.
 inline std::vector<std::pair<int, std::vector<std::pair<int, int>>>> SemiGlobal_mi355x_batch(
     const std::vector<std::array<uint8_t, 16384>> &seq1s, const std::vector<std::array<uint8_t, 16384>> &seq2s, unsigned threads = 0)
 {
@@ -59,7 +59,7 @@ inline std::vector<std::pair<int, std::vector<std::pair<int, int>>>> SemiGlobal_
     if (n == 0) return out;
     if (threads == 0) threads = std::thread::hardware_concurrency();
     threads = threads < 1 ? 1 : threads > 64 ? 64 : threads;
-    constexpr size_t kSlice = 16384;                   // two of the library's internal chunks: its copies and kernels overlap inside a call
+    constexpr size_t kSlice = 65536;                   // two of the library's internal chunks: its copies and kernels overlap inside a call
     std::vector<int32_t> scores(n);
     std::vector<uint32_t> lengths(n);
     std::vector<uint64_t> moves(n * size_t(SWMI_SG_MOVE_WORDS));
