@@ -151,6 +151,35 @@ __global__ void __launch_bounds__(256) expand_shape_kernel(v4u *__restrict__ dst
     }
 }
 
+// What a ONE-SHOT expand would look like: one wavefront per 4 KB chunk of a region (33 chunks used per 128 KB region), which
+// first reads the part of the region's 4 KB of move words that lies before (or behind) its chunk -- whichever is shorter,
+// 64 words per pass, cache hits after the region's first wavefront -- and then writes its 4 KB.
+template <int STORES, bool PREFIX>                       // STORES x 1 KB per wavefront
+__global__ void __launch_bounds__(256) expand_flat_shape_kernel(v4u *__restrict__ dst, const unsigned long long *__restrict__ moves,
+                                                                size_t region16, int chunks, unsigned value)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (size_t)blockIdx.x * 4 + wv;
+    const size_t r = wave / chunks;
+    const int j = (int)(wave % chunks);
+    const unsigned long long *mine = moves + r * 520;     // 4160 bytes of moves per region
+    const int before = j * 16, behind = (chunks - j) * 16;               // (in words of 32 moves = 256 bytes of positions)
+    const int first = before <= behind ? 0 : before, words = !PREFIX ? 0 : (before <= behind ? before : behind) * STORES / 4;
+    unsigned long long acc = 0;
+    for (int w = lane; w < words; w += 64) acc += __popcll(mine[first + w]);
+    unsigned red = (unsigned)acc;
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x111, 0xf, 0xf, true);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x112, 0xf, 0xf, true);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x114, 0xf, 0xf, true);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x118, 0xf, 0xf, true);
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)red, 15) + (unsigned)__builtin_amdgcn_readlane((int)red, 31) +
+                         (unsigned)__builtin_amdgcn_readlane((int)red, 47) + (unsigned)__builtin_amdgcn_readlane((int)red, 63);
+    const v4u v = {value + tot, value + 1, value + 2, value + 3};
+    v4u *out = dst + r * region16 + (size_t)j * (64 * STORES);
+#pragma unroll
+    for (int q = 0; q < STORES; ++q) __builtin_nontemporal_store(v, out + 64 * q + lane);
+}
+
 static double time_ms(hipStream_t st, int reps, const std::function<void()> &launch)
 {
     hipEvent_t a, b;
@@ -243,6 +272,20 @@ int main(int argc, char **argv)
         ms = time_ms(st, 9, [&] { hipLaunchKernelGGL((expand_shape_kernel<true>), dim3((unsigned)(regions / 4)), dim3(256), 0, st, a, region / 16, 7u); });
         printf("%-60s %8.3f ms  %6.2f TB/s\n", "expand shape: four wavefronts per region, 16 KB per trip", ms, moved / ms / 1e9);
         fflush(stdout);
+        // one-shot forms: one wavefront per 4 KB / 1 KB chunk of a region, with and without the prefix over the move words (buffer b)
+#define FLAT_CASE(STORES, PREFIX, LABEL)                                                                                     \
+        {                                                                                                                    \
+            const int chunks = 128 / STORES;                                                                                 \
+            ms = time_ms(st, 9, [&] { hipLaunchKernelGGL((expand_flat_shape_kernel<STORES, PREFIX>), dim3((unsigned)(regions * chunks / 4)), dim3(256), 0, st, a, \
+                                                         reinterpret_cast<const unsigned long long *>(b), region / 16, chunks, 7u); }); \
+            printf("%-60s %8.3f ms  %6.2f TB/s\n", LABEL, ms, moved / ms / 1e9);                                             \
+            fflush(stdout);                                                                                                  \
+        }
+        FLAT_CASE(4, true, "expand shape: one wavefront per 4 KB chunk, prefix from moves")
+        FLAT_CASE(4, false, "expand shape: one wavefront per 4 KB chunk, no prefix")
+        FLAT_CASE(1, true, "expand shape: one wavefront per 1 KB chunk, prefix from moves")
+        FLAT_CASE(1, false, "expand shape: one wavefront per 1 KB chunk, no prefix")
+#undef FLAT_CASE
     }
     CHECK(hipFree(a));
     CHECK(hipFree(b));
