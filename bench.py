@@ -58,41 +58,62 @@ REFERENCE_PUBLISHED_ALIGN_PER_S = 1e6 / 4.4    # README.md:4 of the reference: s
 CONFIG3_PAIRS_PER_GPU = 1 << 26                # BASELINE.json configs[3]: 512M pairs over 8 GPUs
 
 
-def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None, conditional_share=1.0):
+def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None, conditional_share=1.0, pick="innermost", second=None):
     """VALU issue-bound utilisation of one launch, derived from the shipped library's disassembly (tools/isa_census.py).
 
     `trips` = iterations of the main loop AS WRITTEN IN THE SOURCE; `marker` = (mnemonic, count per source iteration):
     hipcc unrolls some instantiations, and the number of marker instructions in the compiled loop body says by how much.
     `conditional_share` = on which share of the iterations the loop's blocks under a scalar condition run (the semi-global
-    sweep flushes its records every 16th round).
+    sweep flushes its records every 16th round).  `pick`: how the marker picks the loop (isa_census.census).
+    `second` = {"marker": (mnemonic, per iteration), "exclude": mnemonic, "trips": n}: a SECOND hot loop of the same kernel
+    (the semi-global sweeps' calm loop: the one without the X-drop test) that ran n source iterations; `trips` then counts
+    the first loop's only.
     Returns the dict that goes into a `roofline` object: achieved / peak in G SIMD-issue-cycles per second and
     frac = achieved / peak <= 1 by construction (a kernel cannot issue more VALU cycles than elapsed)."""
     try:
         import isa_census
-        found = isa_census.census_for(kernel_regex, marker_op=marker[0] if marker else None)
-        if len(found) != 1:
-            raise RuntimeError("%d kernels match %r" % (len(found), kernel_regex))
-        name, c = next(iter(found.items()))
-        if marker:
-            unroll = (c["main_loop"]["by_op"].get(marker[0], 0)) / float(marker[1])
-            if unroll < 1:
-                raise RuntimeError("main loop of %s holds %d %s, fewer than one source iteration's %d" % (
-                    name, c["main_loop"]["by_op"].get(marker[0], 0), marker[0], marker[1]))
-            trips = trips / unroll
+
+        def one(marker, exclude, pick, trips):
+            found = isa_census.census_for(kernel_regex, marker_op=marker[0] if marker else None, exclude_op=exclude, pick=pick)
+            if len(found) != 1:
+                raise RuntimeError("%d kernels match %r" % (len(found), kernel_regex))
+            name, c = next(iter(found.items()))
+            if marker:
+                unroll = (c["main_loop"]["by_op"].get(marker[0], 0)) / float(marker[1])
+                if unroll < 1:
+                    raise RuntimeError("main loop of %s holds %d %s, fewer than one source iteration's %d" % (
+                        name, c["main_loop"]["by_op"].get(marker[0], 0), marker[0], marker[1]))
+                trips = trips / unroll
+            return name, c, trips
+        name, c, trips = one(marker, None, pick, trips)
+        c2 = trips2 = None
+        if second:
+            _, c2, trips2 = one(second["marker"], second.get("exclude"), "most", second["trips"])
     except Exception as e:                  # no llvm-objdump on this box: say so, never invent a fraction
         return {"frac": None, "census_error": repr(e)}
     kernel_s = kernel_ms * 1e-3
     cyc_ideal = isa_census.issue_cycles_per_wave(c, trips, "ideal", conditional_share)
     cyc_meas = isa_census.issue_cycles_per_wave(c, trips, "measured", conditional_share)
+    valu = isa_census.valu_instructions_per_wave(c, trips, conditional_share)
+    if c2 is not None:                      # the second loop sits in the first census's "outside" part once: take that out, put its trips in
+        for key, rates in (("issue_cycles_ideal", "ideal"), ("issue_cycles_measured_rates", "measured")):
+            body = c2["main_loop"][key] + conditional_share * c2["main_loop_conditional"][key]
+            static = c2["main_loop"][key] + c2["main_loop_conditional"][key]
+            if rates == "ideal":
+                cyc_ideal += trips2 * body - static
+            else:
+                cyc_meas += trips2 * body - static
+        valu += trips2 * (c2["main_loop"]["valu"] + conditional_share * c2["main_loop_conditional"]["valu"]) - (
+            c2["main_loop"]["valu"] + c2["main_loop_conditional"]["valu"])
     achieved = waves * cyc_ideal / kernel_s
-    return {
+    out = {
         "bound": "valu", "kernel": name, "kernel_code_sha256": c["code_sha256"],
         "achieved": round(achieved / 1e9, 1), "peak": round(SIMD_CYCLES_PER_S / 1e9, 1), "unit": "G VALU issue cycles/s (sum over 1024 SIMDs)",
         "frac": round(achieved / SIMD_CYCLES_PER_S, 4),
         "frac_at_measured_instruction_rates": round(waves * cyc_meas / kernel_s / SIMD_CYCLES_PER_S, 4),
         "census": {"source": "tools/isa_census.py on the libswmi.so being timed (class costs: profiles/r01_microbench_valu_rate*.txt)",
                    "main_loop_trips": round(trips, 2), "wavefronts_per_launch": waves,
-                   "valu_instructions_per_wavefront": round(isa_census.valu_instructions_per_wave(c, trips, conditional_share)),
+                   "valu_instructions_per_wavefront": round(valu),
                    "issue_cycles_per_wavefront": round(cyc_ideal, 1),
                    "main_loop_valu_by_op": c["main_loop"]["by_op"],
                    "main_loop_issue_cycles": c["main_loop"]["issue_cycles_ideal"],
@@ -100,6 +121,11 @@ def issue_bound(kernel_regex, trips, waves, kernel_ms, marker=None, conditional_
                    "conditional_share": conditional_share,
                    "unmeasured_valu_in_main_loop": c["main_loop"]["unmeasured_valu"]},
     }
+    if c2 is not None:
+        out["census"]["second_loop"] = {"trips": round(trips2, 2), "valu": c2["main_loop"]["valu"], "valu_by_op": c2["main_loop"]["by_op"],
+                                        "issue_cycles": c2["main_loop"]["issue_cycles_ideal"],
+                                        "conditional_issue_cycles": c2["main_loop_conditional"]["issue_cycles_ideal"]}
+    return out
 
 
 def stamped_profile(kernel_code_sha256):
@@ -363,8 +389,8 @@ def arith_dtype(kernel_name):
 
 def sg_sweep_shape(kernel_name):
     """(alignments per wavefront, census marker) of a semi-global sweep kernel as swmi_semiglobal_kernels_for_batch names it:
-    64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes; the sweeps' round loop is unrolled by two and the
-    X-drop test's one v_pk_ashrrev_i16 per register (two cells) marks a round."""
+    64 / 32 / 16 alignments per wavefront with the band in 1 / 2 / 4 lanes; the sweeps' exact loop holds eight rounds and the
+    X-drop test's one v_pk_ashrrev_i16 per register (two cells) marks a round (the calm loop has none: bench_semiglobal)."""
     name = kernel_name.replace(" ", "")
     if name.startswith("sg_forward_lane_kernel<"):
         return 64, ("v_pk_ashrrev_i16", 16)
@@ -428,9 +454,16 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     sweep_kernel, tb_kernel = swmi.semiglobal_kernels_for_batch(P)          # the library says which mapping it ran
     name = sweep_kernel.replace(" ", "")
     per_wave, marker = sg_sweep_shape(name)
-    # the record flush + stream top-up block runs on every 16th round; the loop holds two rounds and hipcc keeps one copy
-    # of the block behind each, so of the conditional instructions the census finds in a trip 1/16 run on average
-    roof = issue_bound("^" + name + "$", rounds, (P + per_wave - 1) // per_wave, sweep_ms, marker=marker, conditional_share=1.0 / 16)
+    # Two loops of eight unrolled rounds each: the exact one (X-drop test: the marker) and the calm one (sg_kernels.hip: windows in
+    # which no cell can reach the threshold); the library counts how many windows of the last call were calm.  The record
+    # flush + stream top-up block runs on every 16th round and hipcc keeps one copy behind each of a loop's eight rounds, so of
+    # the conditional instructions the census finds in a trip 1/16 run on average.
+    windows, calm_windows = swmi.semiglobal_window_stats(stream.cuda_stream)
+    calm_share = calm_windows / windows if windows else 0.0
+    roof = issue_bound("^" + name + "$", rounds * (1.0 - calm_share), (P + per_wave - 1) // per_wave, sweep_ms, marker=marker,
+                       conditional_share=1.0 / 16, pick="most",
+                       second={"marker": ("v_pk_maximum3_f16", marker[1] * 3 // 2), "exclude": marker[0], "trips": rounds * calm_share})
+    roof["calm_window_share"] = round(calm_share, 4)
     traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
     roof.update({
         "kernel_ms": round(sweep_ms, 3), "traceback_kernels": tb_kernel, "traceback_kernel_ms": round(tb_ms, 3),
@@ -443,6 +476,18 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
                 "note": "sequences in + (i, j) pairs out; the predecessor records between the two kernels are implementation "
                         "traffic on top"}})
     line["roofline"] = roof
+    # the same call with every round on the exact path (what a batch of alignments that hover at their X-drop thresholds runs)
+    forced = os.environ.get("SWMI_SG_EXACT") == "1"
+    swmi.semiglobal_set_exact(True)
+    try:
+        ph = [swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap,
+                                          lengths.data_ptr(), stream.cuda_stream) for _ in range(3)]
+    finally:
+        swmi.semiglobal_set_exact(forced)
+    ex_sweep, ex_tb = sum(p[0] for p in ph) / 3, sum(p[1] for p in ph) / 3
+    line["exact_path_forced"] = {"sweep_ms": round(ex_sweep, 3), "traceback_ms": round(ex_tb, 3),
+                                 "value": round(P / ((ex_sweep + ex_tb) * 1e-3), 1), "unit": "alignments/s",
+                                 "note": "swmi_semiglobal_set_exact(1): no calm windows, the X-drop test in every round; same results"}
     # Two calls in flight on two streams (the library keeps a workspace per stream: tests/test_gpu_multi.py): the second
     # call's sweep shares the SIMDs with the first one's -- two wavefronts per SIMD issue 2 instructions per ~4.5 cycles where
     # one issues 1 per ~5 -- and the tracebacks run under the other call's sweep.  Same per-call batch, same results; a

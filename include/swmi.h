@@ -276,6 +276,15 @@ SWMI_API int swmi_semiglobal_expand_moves(const uint64_t *moves, uint32_t length
  * SWMI_ERR_INVALID_ARGUMENT.  Process-wide, one atomic word.  SWMI_SG_SWEEP in the environment sets the initial value at
  * swmi_init* (a value this call would reject is ignored).  (The traceback has one mapping: a lane per walk + expand kernel.) */
 SWMI_API int swmi_semiglobal_set_mapping(int sweep);
+/* The sweeps skip the X-drop test in windows of 16 rounds in which no band cell of the wavefront's alignments can reach the
+ * threshold (a margin test once per window, DESIGN.md section 10: the same results by construction).  exact_only = 1 makes
+ * every round run the test (A/B, tests); 0 = default.  Process-wide; SWMI_SG_EXACT in the environment gives the initial
+ * value at swmi_init*. */
+SWMI_API int swmi_semiglobal_set_exact(int exact_only);
+/* What the last swmi_semiglobal_xdrop[_moves]_device call on `stream` of the current GPU ran: counts[0] = windows of 8 rounds
+ * summed over its sweep wavefronts, counts[1] = how many of them were calm (no X-drop test).  Waits for the stream.
+ * SWMI_ERR_INVALID_ARGUMENT when no call has run on that stream. */
+SWMI_API int swmi_semiglobal_window_stats(void *stream, uint64_t counts[2]);
 /* Free the per-stream workspaces of the current GPU (synchronises the device first). */
 SWMI_API int swmi_semiglobal_release_workspaces(void);
 /* Names of the sweep and traceback kernels a call with n alignments runs on the current GPU (the mapping depends on the

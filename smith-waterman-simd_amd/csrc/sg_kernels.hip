@@ -212,6 +212,12 @@ __device__ __forceinline__ unsigned sg_pk_max3(unsigned a, unsigned b, unsigned 
                                                      __builtin_bit_cast(sg_half2, c));
     return __builtin_bit_cast(unsigned, m);
 }
+__device__ __forceinline__ unsigned sg_pk_min3(unsigned a, unsigned b, unsigned c)
+{
+    const sg_half2 m = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(sg_half2, a), __builtin_bit_cast(sg_half2, b)),
+                                                     __builtin_bit_cast(sg_half2, c));
+    return __builtin_bit_cast(unsigned, m);
+}
 __device__ __forceinline__ unsigned sg_pk_below(unsigned v, unsigned limit)      // 0xFFFF in every half with v < limit (both < 0x8000)
 {
     const sg_short2 d = (__builtin_bit_cast(sg_short2, v) - __builtin_bit_cast(sg_short2, limit)) >> 15;
@@ -269,7 +275,8 @@ __device__ __forceinline__ void sg_keep_f16_denormals()                         
 template <int G, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
-                        uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
+                        uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary, int exact_only,
+                        uint32_t *__restrict__ window_stats)
 {
     constexpr int C = 32 / G;                             // band cells per lane
     constexpr int A = 64 / G;                             // alignments per wavefront
@@ -365,7 +372,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     feed.start(is_last ? stream_b : stream_a, kStreamStride, is_last ? 0 : 31);       // next character: seq2[0] / seq1[31]
 
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
-    auto one_round = [&](const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
+    auto one_round = [&](auto calm_tag, const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
+        constexpr bool kCalm = decltype(calm_tag)::value;   // a round of a calm window (see the loop below): no cell can fall under the threshold
         // source.cpp:1895: band cell 0 (first lane, register 0, low half) against band cell 31 (last lane, last register, high half)
         // All of a round's decisions are arithmetic masks (sign of a difference, shifted down): a compare writes a scalar
         // register pair and the select that reads it waits for it -- with one or two wavefronts on the SIMD nothing fills that wait
@@ -471,17 +479,23 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         // derived only from dropped cells (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
         --off;
         const int stored = kmax >> 7, band_best = stored + off;
-        const int round_best = max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
+        // (calm: the band maximum is a live cell, true value >= the threshold >= 1)
+        const int round_best = kCalm ? band_best : max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
         const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = pick(imask, round_best, best);
         best_round = pick(imask, round, best_round);
         best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
         best_top = pick(imask, pos_y, best_top);
         const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941, and "0 means dropped"
-        const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);     // v_mul_u32_u24, full rate
+        if constexpr (kCalm) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k)                  // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
-            cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+            for (int k = 0; k < NV; ++k) cur[k] &= (int)~((unsigned)(kScale - 1) * 0x10001u);     // every cell stays above the threshold
+        } else {
+            const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);     // v_mul_u32_u24, full rate
+#pragma unroll
+            for (int k = 0; k < NV; ++k)              // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
+                cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+        }
         if (C == 8) {
             my_stage0[8 * (round & 15)] = (uint8_t)tags;
             my_stage0[8 * (round & 15) + 1] = (uint8_t)(tags >> 16);
@@ -505,18 +519,64 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
             off += delta;
         }
-        alive_m &= keep_opaque(-round_best) >> 31;        // alive && round_best != 0 (:1943-1946)
+        if constexpr (!kCalm) alive_m &= keep_opaque(-round_best) >> 31;      // alive && round_best != 0 (:1943-1946)
         last_round = round;
     };
 
-    // kMaxRound is odd: rounds 1 .. kMaxRound - 1 in pairs.  "Has every alignment of the wavefront ended" is asked once per
-    // 16 rounds, not per round: the test is a vector compare feeding a scalar branch, which drains the wavefront's pipeline;
-    // the up to 15 rounds a finished wavefront runs on change nothing (no alignment is alive to improve, and the records of
-    // rounds after an alignment's best round are never read).
-    for (int round = 1; round < kMaxRound; round += 2) {
-        if ((round & 15) == 1 && !__any(alive_m != 0)) break;
-        one_round(round, sp_a, sp_b);
-        one_round(round + 1, sp_b, sp_a);
+    // CALM WINDOWS.  Every kCalmWindow rounds the wavefront asks whether any of its live alignments has a band cell closer
+    // than kCalmMargin to the X-drop threshold.  If none has, no cell can be dropped in the next kCalmWindow rounds: in stored
+    // terms a cell never falls below the lowest cell of the band before it (every cell has a gap parent inside the band, and
+    // a gap step adds 0), while the threshold climbs by one per round plus the rise of `best`, which is at most one per two
+    // rounds (a diagonal step takes two) -- 12 in 8 rounds.  Those rounds then run without the X-drop test (one v_and per
+    // register instead of compare, mask, apply) and without the guards for a dropped band maximum: the same results by
+    // construction.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of every alignment) or
+    // exact_only send the window down the exact path.  Two loops, one per kind of window, each running for as long as its
+    // kind lasts: hipcc gives the two bodies different register assignments, and the moves between them are paid only where
+    // the kind changes.  ("Has every alignment of the wavefront ended" is asked at the same place, not per round: a vector
+    // compare feeding a scalar branch drains the wavefront's pipeline; the rounds a finished wavefront runs on change nothing
+    // -- no alignment is alive to improve, and the records of rounds after an alignment's best round are never read.)
+    constexpr int kCalmWindow = 8, kCalmMargin = kCalmWindow + kCalmWindow / 2 + 1;
+    static_assert((kMaxRound - 1) % 16 == 0 && 16 % kCalmWindow == 0, "whole windows");
+    auto window_kind = [&]() -> int {                     // 1 calm, 0 exact, -1 every alignment of the wavefront has ended
+        if (!__any(alive_m != 0)) return -1;
+        unsigned low;                                     // the lowest of this lane's cells (the vote below covers the band's other lanes)
+        if constexpr (NV == 8) low = sg_pk_min3(sg_pk_min3((unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2]), sg_pk_min3((unsigned)cur[3], (unsigned)cur[4], (unsigned)cur[5]),
+                                                sg_pk_min3((unsigned)cur[6], (unsigned)cur[7], (unsigned)cur[7]));
+        else                   low = sg_pk_min3(sg_pk_min3((unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2]), (unsigned)cur[3], (unsigned)cur[3]);
+        const int low_stored = (int)min(low & 0xFFFFu, low >> 16) >> 7;
+        const int thr_now = (best - kXDrop > 1 ? best - kXDrop : 1) - off;
+        const bool edgy = alive_m != 0 && low_stored < thr_now + kCalmMargin;
+        return !exact_only && !__any(edgy) ? 1 : 0;
+    };
+    int round = 1, kind = window_kind();
+    uint32_t calm_windows = 0;                            // (scalar: the loops are wavefront-uniform)
+    while (kind >= 0) {
+        if (kind == 1) {
+            do {
+#pragma unroll
+                for (int k = 0; k < kCalmWindow; k += 2) {
+                    one_round(std::true_type(), round + k, sp_a, sp_b);
+                    one_round(std::true_type(), round + k + 1, sp_b, sp_a);
+                }
+                round += kCalmWindow;
+                ++calm_windows;
+                kind = round < kMaxRound ? window_kind() : -1;
+            } while (kind == 1);
+        } else {
+            do {
+#pragma unroll
+                for (int k = 0; k < kCalmWindow; k += 2) {
+                    one_round(std::false_type(), round + k, sp_a, sp_b);
+                    one_round(std::false_type(), round + k + 1, sp_b, sp_a);
+                }
+                round += kCalmWindow;
+                kind = round < kMaxRound ? window_kind() : -1;
+            } while (kind == 0);
+        }
+    }
+    if (lane == 0) {                                      // windows run / of them calm, summed over the launch (swmi_semiglobal_window_stats)
+        atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
+        atomicAdd(&window_stats[1], calm_windows);
     }
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     if (real && is_first) {
@@ -536,7 +596,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
 template <int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
 sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t n,
-                       uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary)
+                       uint32_t *__restrict__ codes, uint32_t *__restrict__ dirs, int4 *__restrict__ summary, int exact_only,
+                       uint32_t *__restrict__ window_stats)
 {
     constexpr int NV = 16, A = 64;
     __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]: one 128-byte line each per flush
@@ -592,7 +653,8 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     stage_codes[lane][0] = make_uint2(0, 0);
 
-    auto one_round = [&](const int round, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
+    auto one_round = [&](auto calm_tag, const int round, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
+        constexpr bool kCalm = decltype(calm_tag)::value;   // a round of a calm window (below): no cell can fall under the threshold
         // source.cpp:1895: band cell 0 against band cell 31.  All of a round's decisions are arithmetic masks (sign of a
         // difference, shifted down): a compare writes a scalar register pair and the select that reads it waits for it, and
         // with one wavefront on the SIMD nothing fills that wait
@@ -623,7 +685,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             even[w] = ~dw[w] & kByteOnes;
-            odd[w] = ~(dw[w] >> 4) & kByteOnes;
+            odd[w] = __builtin_amdgcn_bitop3_b32(dw[w] >> 4, kByteOnes, 0u, 0x0C);     // ~a & b in one (hipcc: v_not, shift, v_and)
         }
         // S of cells (k, k + 16), k = 0 .. 16: left of register k is sv[k], up is sv[k + 1]; past the band's ends: dropped (0)
         unsigned sv[NV + 1];
@@ -675,17 +737,24 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         // (0) is <= 3 and stands for "<= 0" (the reference's guard, source.cpp:1922-1924)
         --off;
         const int stored = kmax >> 7, band_best = stored + off;
-        const int round_best = max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
+        // (calm: the band maximum is a live cell, true value >= the threshold >= 1)
+        const int round_best = kCalm ? band_best : max(band_best, 0) & (keep_opaque(3 - stored) >> 31);
         const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = (int)pick(imask, (unsigned)round_best, (unsigned)best);
         best_round = (int)pick(imask, (unsigned)round, (unsigned)best_round);
         best_lane = (int)pick(imask, (unsigned)(kmax >> 2) & 31u, (unsigned)best_lane);  // highest cell among equals (:1957)
         best_top = (int)pick(imask, (unsigned)pos_y, (unsigned)best_top);
         const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941
-        const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);
+        if constexpr (kCalm) {                            // every cell stays above the threshold
 #pragma unroll
-        for (int k = 0; k < NV; ++k)                      // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
-            cur[k] = __builtin_amdgcn_bitop3_b32(v[k], sg_pk_below(v[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+            for (int k = 0; k < NV; ++k) cur[k] = v[k] & ~((unsigned)(kScale - 1) * 0x10001u);
+        } else {
+            const unsigned thr2 = __umul24((unsigned)(thr_true - off), (unsigned)kScale * 0x10001u);
+#pragma unroll
+            for (int k = 0; k < NV; ++k)                  // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
+                cur[k] = __builtin_amdgcn_bitop3_b32(v[k], sg_pk_below(v[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
+            alive_m &= keep_opaque(-round_best) >> 31;    // alive && round_best != 0 (:1943-1946)
+        }
         stage_codes[lane][round & 15] = make_uint2(tags_lo, tags_hi);
         if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
             flush_codes(round >> 4);
@@ -704,14 +773,59 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
             for (int k = 0; k <= NV; ++k) sp_next[k] = sg_pk_sub_sat(sp_next[k], d2);
             off += delta;
         }
-        alive_m &= keep_opaque(-round_best) >> 31;        // alive && round_best != 0 (:1943-1946)
         last_round = round;
     };
 
-    for (int round = 1; round < kMaxRound; round += 2) {  // (the exit test once per 16 rounds: see the split sweep)
-        if ((round & 15) == 1 && !__any(alive_m != 0)) break;
-        one_round(round, sp_a, sp_b);
-        one_round(round + 1, sp_b, sp_a);
+    // CALM WINDOWS.  Every kCalmWindow rounds the wavefront asks whether any of its live alignments has a band cell closer
+    // than kCalmMargin to the X-drop threshold.  If none has, no cell can be dropped in the next kCalmWindow rounds: in stored
+    // terms a cell never falls below the lowest cell of the band before it (every cell has a gap parent inside the band, and
+    // a gap step adds 0), while the threshold climbs by one per round plus the rise of `best`, which is at most one per two
+    // rounds (a diagonal step takes two) -- 12 in 8 rounds.  Those rounds then run without the X-drop test (one v_and per
+    // register instead of compare, mask, apply) and without the guards for a dropped band maximum: the same results by
+    // construction, 14 % fewer instructions.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of
+    // every alignment) or exact_only send the window down the exact path.  Two loops, one per kind of window, each running
+    // for as long as its kind lasts: hipcc gives the two bodies different register assignments, and the ~180 moves between them
+    // are paid only where the kind changes.
+    constexpr int kCalmWindow = 8, kCalmMargin = kCalmWindow + kCalmWindow / 2 + 1;
+    static_assert((kMaxRound - 1) % 16 == 0 && 16 % kCalmWindow == 0, "whole windows");
+    auto window_kind = [&]() -> int {                     // 1 calm, 0 exact, -1 every alignment of the wavefront has ended
+        if (!__any(alive_m != 0)) return -1;
+        const unsigned low = sg_pk_min3(sg_pk_min3(sg_pk_min3(cur[0], cur[1], cur[2]), sg_pk_min3(cur[3], cur[4], cur[5]), sg_pk_min3(cur[6], cur[7], cur[8])),
+                                        sg_pk_min3(sg_pk_min3(cur[9], cur[10], cur[11]), sg_pk_min3(cur[12], cur[13], cur[14]), cur[15]), cur[15]);
+        const int low_stored = (int)min(low & 0xFFFFu, low >> 16) >> 7;
+        const int thr_now = (best - kXDrop > 1 ? best - kXDrop : 1) - off;
+        const bool edgy = alive_m != 0 && low_stored < thr_now + kCalmMargin;
+        return !exact_only && !__any(edgy) ? 1 : 0;
+    };
+    int round = 1, kind = window_kind();
+    uint32_t calm_windows = 0;                            // (scalar: the loops are wavefront-uniform)
+    while (kind >= 0) {
+        if (kind == 1) {
+            do {
+#pragma unroll
+                for (int k = 0; k < kCalmWindow; k += 2) {
+                    one_round(std::true_type(), round + k, sp_a, sp_b);
+                    one_round(std::true_type(), round + k + 1, sp_b, sp_a);
+                }
+                round += kCalmWindow;
+                ++calm_windows;
+                kind = round < kMaxRound ? window_kind() : -1;
+            } while (kind == 1);
+        } else {
+            do {
+#pragma unroll
+                for (int k = 0; k < kCalmWindow; k += 2) {
+                    one_round(std::false_type(), round + k, sp_a, sp_b);
+                    one_round(std::false_type(), round + k + 1, sp_b, sp_a);
+                }
+                round += kCalmWindow;
+                kind = round < kMaxRound ? window_kind() : -1;
+            } while (kind == 0);
+        }
+    }
+    if (lane == 0) {                                      // windows run / of them calm, summed over the launch (swmi_semiglobal_window_stats)
+        atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
+        atomicAdd(&window_stats[1], calm_windows);
     }
     if ((last_round & 15) != 15) flush_codes(last_round >> 4);
     if (real) {
@@ -1073,9 +1187,11 @@ inline size_t dirs_bytes(size_t n) { return round16(n * (size_t)kDirWords * size
 inline size_t streams_bytes(size_t n) { return round16(((n + 63) / 64 * 64) * 2 * (size_t)kStreamWords * sizeof(unsigned long long)); }   // whole blocks of 64 / 32 / 16
 inline size_t moves_bytes(size_t n) { return round16(n * (size_t)kMoveWords * sizeof(unsigned long long)); }
 
+constexpr size_t kStatsBytes = 128;                       // window counters of the sweep, at the start of the workspace
+
 size_t semiglobal_workspace_bytes(size_t n)
 {
-    return codes_bytes(n) + dirs_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
+    return kStatsBytes + codes_bytes(n) + dirs_bytes(n) + round16(n * sizeof(int4)) + streams_bytes(n) + moves_bytes(n);
 }
 
 namespace {
@@ -1127,7 +1243,14 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
                              hipEvent_t between, int compute_units, SgTuning tuning, unsigned long long *d_moves_out)
 {
     if (n == 0) return hipSuccess;
-    char *ws = static_cast<char *>(d_workspace);
+    // the first line of the workspace: windows of the last launch's sweep wavefronts, [0] all, [1] calm (64-bit sums would need
+    // nothing more: 4096 wavefronts x 4096 windows stay below 2^32)
+    uint32_t *window_stats = static_cast<uint32_t *>(d_workspace);
+    {
+        const hipError_t ez = hipMemsetAsync(window_stats, 0, kStatsBytes, stream);
+        if (ez != hipSuccess) return ez;
+    }
+    char *ws = static_cast<char *>(d_workspace) + kStatsBytes;
     uint32_t *codes = reinterpret_cast<uint32_t *>(ws);
     uint32_t *top = reinterpret_cast<uint32_t *>(ws + codes_bytes(n));          // the band's move bits (kDirWords x n)
     int4 *summary = reinterpret_cast<int4 *>(ws + codes_bytes(n) + dirs_bytes(n));
@@ -1145,9 +1268,9 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
                            (uint32_t)n, streams, per_block);
         const dim3 grid4((unsigned)((n + 15) / 16)), grid2((unsigned)((n + 31) / 32)), grid1((unsigned)((n + 63) / 64));
 #define SWMI_SG_LAUNCH1(W) \
-    hipLaunchKernelGGL((sg_forward_lane_kernel<W>), grid1, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+    hipLaunchKernelGGL((sg_forward_lane_kernel<W>), grid1, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary, tuning.exact_only, window_stats)
 #define SWMI_SG_LAUNCH(G, W, GRID) \
-    hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary)
+    hipLaunchKernelGGL((sg_forward_split_kernel<G, W>), GRID, dim3(64), 0, stream, streams, (uint32_t)n, codes, top, summary, tuning.exact_only, window_stats)
         switch (sweep) {
         case 41: SWMI_SG_LAUNCH(4, 1, grid4); break;
         case 42: SWMI_SG_LAUNCH(4, 2, grid4); break;

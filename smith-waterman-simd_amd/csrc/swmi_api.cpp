@@ -91,6 +91,7 @@ void read_knobs()
     k.banded_no_i16 = getenv("SWMI_BANDED_NO_I16") != nullptr;
     k.banded_no_pk = getenv("SWMI_BANDED_NO_PK") != nullptr;
     k.sg_sweep = (int)num("SWMI_SG_SWEEP", 1, 44, -1);
+    k.sg_exact = (int)num("SWMI_SG_EXACT", 0, 1, -1);
     const char *gb = getenv("SWMI_GATHER_BACKEND");
     k.gather_p2p = gb && strcmp(gb, "p2p") == 0;
     k.gather_piece = (size_t)num("SWMI_TEST_GATHER_PIECE", 1, 1ll << 40, 0);
@@ -711,6 +712,7 @@ int init_list(const int *devices, int n)
     // like SWMI_LANES above: the environment gives an initial value only when it is set; a mapping the program chose
     // through swmi_semiglobal_set_mapping survives a shutdown / re-init
     if (knobs().sg_sweep >= 0 && swmi_semiglobal_set_mapping(knobs().sg_sweep) != SWMI_OK) (void)swmi_semiglobal_set_mapping(-1);
+    if (knobs().sg_exact >= 0) (void)swmi_semiglobal_set_exact(knobs().sg_exact ? 1 : 0);
     return SWMI_OK;
 }
 
@@ -982,6 +984,7 @@ static swmi::SgTuning sg_tuning()
     const uint64_t m = sg_mapping_word().load(std::memory_order_relaxed);
     swmi::SgTuning t;
     t.force_sweep = int(m & 0xffffffffu) - 1;
+    t.exact_only = int((m >> 32) & 1u);
     return t;
 }
 
@@ -1149,7 +1152,36 @@ int swmi_semiglobal_set_mapping(int sweep)
     const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 13) ||
                           (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44);
     if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..13, 21..24 or 41..44", sweep);
-    sg_mapping_word().store(uint64_t(uint32_t(sweep + 1)));
+    // (the low half of the word; the high half is swmi_semiglobal_set_exact's)
+    uint64_t was = sg_mapping_word().load(std::memory_order_relaxed);
+    while (!sg_mapping_word().compare_exchange_weak(was, (was & ~uint64_t(0xffffffffu)) | uint64_t(uint32_t(sweep + 1)))) {}
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_set_exact(int exact_only)
+{
+    if (exact_only != 0 && exact_only != 1) return fail(SWMI_ERR_INVALID_ARGUMENT, "exact_only %d: 0 or 1", exact_only);
+    uint64_t was = sg_mapping_word().load(std::memory_order_relaxed);
+    while (!sg_mapping_word().compare_exchange_weak(was, (was & 0xffffffffu) | (uint64_t(exact_only) << 32))) {}
+    return SWMI_OK;
+}
+
+int swmi_semiglobal_window_stats(void *stream, uint64_t counts[2])
+{
+    if (!counts) return fail(SWMI_ERR_INVALID_ARGUMENT, "counts is NULL");
+    counts[0] = counts[1] = 0;
+    Context *ctx = current();
+    if (!ctx) return last_status();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lock(ctx->ws_mu);
+    const auto it = ctx->sg_workspaces.find(st);
+    if (it == ctx->sg_workspaces.end() || !it->second.ptr)
+        return fail(SWMI_ERR_INVALID_ARGUMENT, "no semi-global call has run on this stream");
+    uint32_t raw[2] = {0, 0};
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(raw, it->second.ptr, sizeof raw, hipMemcpyDeviceToHost));     // the first words of the workspace (sg_kernels.hip)
+    counts[0] = raw[0];
+    counts[1] = raw[1];
     return SWMI_OK;
 }
 

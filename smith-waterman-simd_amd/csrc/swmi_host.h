@@ -48,6 +48,7 @@ struct Knobs {
     bool banded_no_i16 = false;     // SWMI_BANDED_NO_I16
     bool banded_no_pk = false;      // SWMI_BANDED_NO_PK: never the packed banded-affine kernel (A/B against the int32 cell)
     int sg_sweep = -1;              // SWMI_SG_SWEEP: force a semi-global sweep mapping (sg_kernels.hip choose_sweep)
+    int sg_exact = -1;              // SWMI_SG_EXACT: 1 = the sweeps run the X-drop test every round (no calm windows); initial value only
     bool gather_p2p = false;        // SWMI_GATHER_BACKEND=p2p: never RCCL
     size_t gather_piece = 0;        // SWMI_TEST_GATHER_PIECE: ragged RCCL gather even for equal shards, shards broadcast in
                                     //   pieces of this many scores (rehearses the ragged path with one rank)

@@ -58,6 +58,7 @@ size_t semiglobal_workspace_bytes(size_t n);
 // Override of the sweep mapping (swmi_semiglobal_set_mapping; SWMI_SG_SWEEP gives the initial value at swmi_init): -1 = automatic
 struct SgTuning {
     int force_sweep = -1;        // G or 10 * G + W (sg_kernels.hip choose_sweep)
+    int exact_only = 0;          // 1: no calm windows -- every round runs the X-drop test (A/B and tests; same results either way)
 };
 hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, size_t n, void *d_workspace,
                              int32_t *d_scores, int32_t *d_tracebacks, size_t cap, uint32_t *d_lengths, hipStream_t stream,

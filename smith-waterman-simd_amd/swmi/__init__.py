@@ -102,6 +102,8 @@ def load():
     lib.swmi_semiglobal_expand_moves.argtypes = [vp, ctypes.c_uint32, vp, sz]
     lib.swmi_schedule_for_batch.argtypes = [sz]
     lib.swmi_semiglobal_time_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.swmi_semiglobal_window_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.swmi_semiglobal_set_exact.argtypes = [ctypes.c_int]
     lib.swmi_score_banded_affine.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
     lib.swmi_score_banded_affine_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.swmi_queue_create.argtypes = [sz, vp, i8, ctypes.POINTER(vp)]
@@ -463,6 +465,18 @@ def semiglobal_time_device(d_seq1s, d_seq2s, n, d_scores, d_tracebacks, cap, d_l
 def semiglobal_set_mapping(sweep=-1):
     """Override which semi-global sweep runs (-1 = automatic); see swmi_semiglobal_set_mapping in include/swmi.h."""
     _check(load().swmi_semiglobal_set_mapping(int(sweep)))
+
+
+def semiglobal_set_exact(exact_only=False):
+    """True: the sweeps run the X-drop test in every round (no calm windows); same results, see include/swmi.h."""
+    _check(load().swmi_semiglobal_set_exact(1 if exact_only else 0))
+
+
+def semiglobal_window_stats(stream=0):
+    """(windows of 8 rounds the sweep wavefronts of the last device call on `stream` ran, how many of them were calm)."""
+    c = (ctypes.c_uint64 * 2)()
+    _check(load().swmi_semiglobal_window_stats(ctypes.c_void_p(stream), c))
+    return int(c[0]), int(c[1])
 
 
 def semiglobal_kernels_for_batch(n):

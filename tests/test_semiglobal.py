@@ -335,3 +335,62 @@ def test_gpu_semiglobal_mapping_survives_a_reinit(gpu):
     finally:
         gpu.semiglobal_set_mapping(-1)
         gpu.set_schedule(0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", [41, 21, 11])
+def test_gpu_semiglobal_calm_windows_change_nothing(gpu, sg_kernels, sweep):
+    """The sweeps skip the X-drop test in windows of 8 rounds in which no band cell can reach the threshold (sg_kernels.hip,
+    "CALM WINDOWS"); swmi_semiglobal_set_exact(1) sends every window down the exact path.  Same scores, lengths and moves
+    either way -- on healthy alignments (nearly every window calm), on alignments that die by the X-drop rule and on a batch
+    that mixes them in one wavefront -- and the library's own count says which path ran."""
+    import torch
+    sg_kernels(sweep)
+    rng = np.random.default_rng(4100 + sweep)
+    n = 64
+    a = rng.integers(0, 4, (n, 16384), dtype=np.uint8)
+    b = a.copy()
+    subs = rng.random((n, 16384)) < 0.05
+    b[subs] = (b[subs] + rng.integers(1, 4, int(subs.sum()), dtype=np.uint8)) & 3       # SpeedtestSemiGlobal's inputs
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream()
+
+    def run(x, y, exact):
+        m = len(x)
+        d1, d2 = torch.from_numpy(x.copy()).to(dev), torch.from_numpy(y.copy()).to(dev)
+        d_scores = torch.empty(m, dtype=torch.int32, device=dev)
+        d_len = torch.empty(m, dtype=torch.int32, device=dev)
+        d_moves = torch.zeros(m * gpu.SG_MOVE_WORDS, dtype=torch.int64, device=dev)
+        gpu.semiglobal_set_exact(exact)
+        try:
+            gpu.semiglobal_xdrop_moves_device(d1.data_ptr(), d2.data_ptr(), m, d_scores.data_ptr(), d_moves.data_ptr(), d_len.data_ptr(), st.cuda_stream)
+            windows, calm = gpu.semiglobal_window_stats(st.cuda_stream)
+        finally:
+            gpu.semiglobal_set_exact(False)
+        lengths = d_len.cpu().numpy()
+        moves = d_moves.cpu().numpy().reshape(m, gpu.SG_MOVE_WORDS)
+        used = [moves[k, : (int(lengths[k]) - 1 + 31) // 32].copy() for k in range(m)]   # words past the last step are unspecified
+        for k in range(m):
+            tail = (int(lengths[k]) - 1) % 32
+            if tail and len(used[k]):
+                used[k][-1] &= (1 << (2 * tail)) - 1
+        return d_scores.cpu().numpy(), lengths, used, windows, calm
+
+    s0, l0, m0, w0, c0 = run(a, b, False)
+    s1, l1, m1, w1, c1 = run(a, b, True)
+    assert w0 == w1 > 0 and c1 == 0 and c0 > 0.95 * w0            # healthy alignments: the first windows of every alignment are exact, the rest calm
+    assert np.array_equal(s0, s1) and np.array_equal(l0, l1) and all(np.array_equal(x, y) for x, y in zip(m0, m1))
+    assert int(l0.min()) > 16384                                  # (full-length paths)
+    # alignments that run into the X-drop rule at different places, next to healthy ones in the same wavefront
+    a2, bad = a.copy(), b.copy()
+    for k in range(0, n, 3):                                      # (unrelated random tails would not do: at +1 / -1 / -1 a banded
+        cut = int(rng.integers(200, 16000))                       #  alignment of random DNA still drifts upwards)
+        a2[k, cut:], bad[k, cut:] = 0, 1
+    for k in range(1, n, 7):                                      # a stretch of mismatches the alignment may or may not survive
+        lo = int(rng.integers(1000, 15000))
+        a2[k, lo: lo + 20 + 5 * (k % 9)], bad[k, lo: lo + 20 + 5 * (k % 9)] = 2, 3
+    s2, l2, m2, w2, c2 = run(a2, bad, False)
+    s3, l3, m3, w3, c3 = run(a2, bad, True)
+    assert c3 == 0 and 0 < c2 < w2
+    assert np.array_equal(s2, s3) and np.array_equal(l2, l3) and all(np.array_equal(x, y) for x, y in zip(m2, m3))
+    assert int(l2.min()) < 16384 < int(l2.max())

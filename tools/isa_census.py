@@ -149,10 +149,13 @@ def cost_of(op):
     return "valu_unmeasured", DEFAULT_COST, DEFAULT_COST
 
 
-def census(instrs, marker_op=None):
+def census(instrs, marker_op=None, exclude_op=None, pick="innermost"):
     """Split a kernel at its main loop and price both parts.  Main loop = the backward branch with the largest body, or --
     when marker_op names an instruction the hot loop issues (v_dot4_i32_i8 for the scorers) -- the innermost loop that
-    holds the most of them (a staging loop can be longer than a tight DP loop, and an enclosing loop holds more of everything)."""
+    holds the most of them (a staging loop can be longer than a tight DP loop, and an enclosing loop holds more of everything).
+    pick="most": the SMALLEST loop among those that hold the most markers (the semi-global sweeps: two sibling loops of eight
+    unrolled rounds each, with out-of-line blocks that branch back into them -- "innermost" would take a fragment);
+    exclude_op: loops that hold this instruction are not candidates (the sweeps' calm loop is the one WITHOUT the X-drop test)."""
     start = instrs[0]["addr"]
     loops = []
     for k, ins in enumerate(instrs):
@@ -167,9 +170,16 @@ def census(instrs, marker_op=None):
             return sum(1 for x in instrs[ab[0]:ab[1] + 1] if re.sub(r"_(e32|e64)$", "", x["op"]) == marker_op)
         # innermost: a loop that holds the marker but no other loop that holds it (the packed scorer's sweep sits inside a
         # loop over the wavefront's sets of alignments, whose prologue uses the marker instruction too)
-        holders = [ab for ab in loops if marks(ab) > 0]
+        def count(ab, op):
+            return sum(1 for x in instrs[ab[0]:ab[1] + 1] if re.sub(r"_(e32|e64)$", "", x["op"]) == op)
+        holders = [ab for ab in loops if marks(ab) > 0 and not (exclude_op and count(ab, exclude_op) > 0)]
         inner = [ab for ab in holders if not any(o != ab and ab[0] <= o[0] and o[1] <= ab[1] for o in holders)]
-        if inner:
+        if pick == "most" or exclude_op:
+            if not holders:
+                raise RuntimeError("no loop holds %s%s" % (marker_op, " without " + exclude_op if exclude_op else ""))
+            best = max(marks(ab) for ab in holders)
+            main = min((ab for ab in holders if marks(ab) == best), key=lambda ab: ab[1] - ab[0])
+        elif inner:
             best = max(marks(ab) for ab in inner)
             main = min((ab for ab in inner if marks(ab) == best), key=lambda ab: ab[1] - ab[0])
 
@@ -221,7 +231,7 @@ def census(instrs, marker_op=None):
 _cache = {}
 
 
-def census_for(kernel_regex, lib_path=DEFAULT_LIB, marker_op=None):
+def census_for(kernel_regex, lib_path=DEFAULT_LIB, marker_op=None, exclude_op=None, pick="innermost"):
     """{readable kernel name: census} for the kernels of lib_path whose readable name matches kernel_regex."""
     key = (os.path.abspath(lib_path), os.path.getmtime(lib_path))
     if key not in _cache:
@@ -230,7 +240,7 @@ def census_for(kernel_regex, lib_path=DEFAULT_LIB, marker_op=None):
     for sym, instrs in _cache[key].items():
         name = readable(sym)
         if instrs and re.search(kernel_regex, name):
-            c = census(instrs, marker_op)
+            c = census(instrs, marker_op, exclude_op, pick)
             c["symbol"] = sym
             out[name] = c
     return out
@@ -253,13 +263,15 @@ def main():
     ap.add_argument("--kernel", default=r"^sw128_kernel<4,1,0,0>$", help="regex on the readable kernel name")
     ap.add_argument("--json", default=None)
     ap.add_argument("--marker", default=None, help="instruction that identifies the hot loop (e.g. v_dot4_i32_i8)")
+    ap.add_argument("--exclude", default=None, help="loops that hold this instruction are not candidates for the main loop")
+    ap.add_argument("--pick", default="innermost", choices=["innermost", "most"], help="how the marker picks the loop (see census())")
     ap.add_argument("--list", action="store_true")
     args = ap.parse_args()
     if args.list:
         for sym in disassemble(args.lib):
             print(readable(sym))
         return 0
-    res = census_for(args.kernel, args.lib, args.marker)
+    res = census_for(args.kernel, args.lib, args.marker, args.exclude, args.pick)
     if not res:
         sys.stderr.write("no kernel matches %r\n" % args.kernel)
         return 1
