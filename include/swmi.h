@@ -272,7 +272,7 @@ SWMI_API int swmi_semiglobal_expand_moves(const uint64_t *moves, uint32_t length
 /* Which sweep kernel the aligner runs is chosen from the batch size; this overrides the choice, the
  * way swmi_set_schedule does for the scorer -- every mapping returns the same (score, traceback), tests/test_semiglobal.py
  * runs them all.  sweep: -1 = automatic, 4 / 2 / 1 = the band over 4 / 2 lanes or in one lane (16 / 32 / 64 alignments per
- * wavefront), 10 * lanes + W = that mapping compiled for W wavefronts per SIMD (41..44, 21..24, 11..13: the one-lane kernel's 146 registers fit three wavefronts per SIMD).  Anything else:
+ * wavefront; the build for the most wavefronts per SIMD), 10 * lanes + W = that mapping compiled for W wavefronts per SIMD (41..44, 21..23, 11..12).  Anything else:
  * SWMI_ERR_INVALID_ARGUMENT.  Process-wide, one atomic word.  SWMI_SG_SWEEP in the environment sets the initial value at
  * swmi_init* (a value this call would reject is ignored).  (The traceback has one mapping: a lane per walk + expand kernel.) */
 SWMI_API int swmi_semiglobal_set_mapping(int sweep);

@@ -184,16 +184,18 @@ struct SgStream {
         const unsigned long long add_p = k ? pend << (64 - 4 * k) : 0ull;           // pend's characters behind the 16 - k left
         const unsigned long long add_a = rem ? ahead << (64 - 4 * rem) : 0ull;      // ... then `rem` characters of the word after it
         sreg |= add_p | add_a;
-        if (rem > 0 || from_pend == p_fill) {                                       // pend is used up: `ahead` becomes pend
-            pend = rem < 16 ? ahead >> (4 * rem) : 0ull;
-            p_fill = 16 - rem;
-            const int w = w_next < kStreamWords ? w_next : kStreamWords - 1;         // a band that has left the matrix keeps stepping
-            ahead = words[(size_t)w * stride];
-            ++w_next;
-        } else {
-            pend = from_pend ? pend >> (4 * from_pend) : pend;
-            p_fill -= from_pend;
-        }
+        // pend is used up: `ahead` becomes pend and the next word is requested.  Written WITHOUT a branch around the load: every
+        // lane loads (one that keeps its `ahead` asks for the same word again, a hit) straight into `ahead`, which nothing reads
+        // before the next top-up.  A load under a per-lane condition goes through a temporary + copy, and the copy waits for
+        // the load on the spot: a whole memory latency per 16 rounds with one wavefront on the SIMD.
+        const bool take = rem > 0 || from_pend == p_fill;
+        const unsigned long long pend_take = rem < 16 ? ahead >> (4 * rem) : 0ull;
+        const unsigned long long pend_keep = pend >> (4 * (from_pend & 15));        // (from_pend = 16 only when `take`)
+        pend = take ? pend_take : pend_keep;
+        p_fill = take ? 16 - rem : p_fill - from_pend;
+        w_next += take ? 1 : 0;
+        const int w = w_next - 1 < kStreamWords ? w_next - 1 : kStreamWords - 1;     // a band that has left the matrix keeps stepping
+        ahead = words[(size_t)w * stride];
     }
 };
 
@@ -372,8 +374,12 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     feed.start(is_last ? stream_b : stream_a, kStreamStride, is_last ? 0 : 31);       // next character: seq2[0] / seq1[31]
 
     // one round: reads the previous round's view `sp`, leaves this round's view in `sp_next`
-    auto one_round = [&](auto calm_tag, const int round, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
+    // round = base + K of a window of 8 rounds that starts at base (1 or 9 mod 16): what happens every 16th round is then a
+    // test of one bit of `base` in ONE of the eight unrolled rounds, not a copy of the block behind each
+    auto one_round = [&](auto calm_tag, auto k_tag, const int base, const int (&sp)[NV + 1], int (&sp_next)[NV + 1]) {
         constexpr bool kCalm = decltype(calm_tag)::value;   // a round of a calm window (see the loop below): no cell can fall under the threshold
+        constexpr int K = decltype(k_tag)::value;
+        const int round = base + K;
         // source.cpp:1895: band cell 0 (first lane, register 0, low half) against band cell 31 (last lane, last register, high half)
         // All of a round's decisions are arithmetic masks (sign of a difference, shifted down): a compare writes a scalar
         // register pair and the select that reads it waits for it -- with one or two wavefronts on the SIMD nothing fills that wait
@@ -502,9 +508,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         } else {
             *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
         }
-        if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
+        if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4);
-            feed.top_up(kStreamStride);
             if ((round & 31) == 31) {
                 if (real && is_first) *my_dirs = dir_word;
                 my_dirs += n;
@@ -519,6 +524,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             for (int k = 0; k <= NV; ++k) sp_next[k] = (int)sg_pk_sub_sat((unsigned)sp_next[k], d2);
             off += delta;
         }
+        if (K == 7 && (base & 8)) feed.top_up(kStreamStride);                // after round 0 (mod 16); a stream gives at most 16 characters in 16 rounds
         if constexpr (!kCalm) alive_m &= keep_opaque(-round_best) >> 31;      // alive && round_best != 0 (:1943-1946)
         last_round = round;
     };
@@ -536,7 +542,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // compare feeding a scalar branch drains the wavefront's pipeline; the rounds a finished wavefront runs on change nothing
     // -- no alignment is alive to improve, and the records of rounds after an alignment's best round are never read.)
     constexpr int kCalmWindow = 8, kCalmMargin = kCalmWindow + kCalmWindow / 2 + 1;
-    static_assert((kMaxRound - 1) % 16 == 0 && 16 % kCalmWindow == 0, "whole windows");
+    static_assert((kMaxRound - 1) % 16 == 0 && kCalmWindow == 8, "whole windows; one_round places the 16-round events by K and base");
     auto window_kind = [&]() -> int {                     // 1 calm, 0 exact, -1 every alignment of the wavefront has ended
         if (!__any(alive_m != 0)) return -1;
         unsigned low;                                     // the lowest of this lane's cells (the vote below covers the band's other lanes)
@@ -550,30 +556,37 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     };
     int round = 1, kind = window_kind();
     uint32_t calm_windows = 0;                            // (scalar: the loops are wavefront-uniform)
+#define SWMI_SG_WINDOW(CALM)                                                                                      \
+    one_round(CALM(), std::integral_constant<int, 0>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 1>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 2>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 3>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 4>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 5>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 6>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 7>(), round, sp_b, sp_a);                                        \
+    round += kCalmWindow
     while (kind >= 0) {
+        // vmcnt(0) (gfx9 encoding; the builtin, not inline assembly: hipcc's wait-count pass has to see it) in the block that
+        // enters each loop.  The pass merges what is in flight where the loops meet: a stream word still on its way when one loop
+        // hands over would put an s_waitcnt vmcnt into every trip of the other, where that loop first writes the register the
+        // word was loaded into -- and that wait then catches the loop's OWN top-up load, one memory latency per 16 rounds.
         if (kind == 1) {
+            __builtin_amdgcn_s_waitcnt(0x0070);           // (+ lgkmcnt(0): two identical waits hipcc hoists above the branch -- where they are no use)
             do {
-#pragma unroll
-                for (int k = 0; k < kCalmWindow; k += 2) {
-                    one_round(std::true_type(), round + k, sp_a, sp_b);
-                    one_round(std::true_type(), round + k + 1, sp_b, sp_a);
-                }
-                round += kCalmWindow;
+                SWMI_SG_WINDOW(std::true_type);
                 ++calm_windows;
                 kind = round < kMaxRound ? window_kind() : -1;
             } while (kind == 1);
         } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             do {
-#pragma unroll
-                for (int k = 0; k < kCalmWindow; k += 2) {
-                    one_round(std::false_type(), round + k, sp_a, sp_b);
-                    one_round(std::false_type(), round + k + 1, sp_b, sp_a);
-                }
-                round += kCalmWindow;
+                SWMI_SG_WINDOW(std::false_type);
                 kind = round < kMaxRound ? window_kind() : -1;
             } while (kind == 0);
         }
     }
+#undef SWMI_SG_WINDOW
     if (lane == 0) {                                      // windows run / of them calm, summed over the launch (swmi_semiglobal_window_stats)
         atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
         atomicAdd(&window_stats[1], calm_windows);
@@ -653,8 +666,14 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     stage_codes[lane][0] = make_uint2(0, 0);
 
-    auto one_round = [&](auto calm_tag, const int round, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
+    // the calm loop's windows (below): 2 bits per cell, cell c at bits 2c -- bases only
+    unsigned long long a2 = 0, b2 = 0;
+    // round = base + K of a window of 8 rounds that starts at base (1 or 9 mod 16): what happens every 16th round is then a
+    // test of one bit of `base` in ONE of the eight unrolled rounds, not a copy of the block behind each
+    auto one_round = [&](auto calm_tag, auto k_tag, const int base, const unsigned (&sp)[NV + 1], unsigned (&sp_next)[NV + 1]) {
         constexpr bool kCalm = decltype(calm_tag)::value;   // a round of a calm window (below): no cell can fall under the threshold
+        constexpr int K = decltype(k_tag)::value;
+        const int round = base + K;
         // source.cpp:1895: band cell 0 against band cell 31.  All of a round's decisions are arithmetic masks (sign of a
         // difference, shifted down): a compare writes a scalar register pair and the select that reads it waits for it, and
         // with one wavefront on the SIMD nothing fills that wait
@@ -665,7 +684,25 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         const int pos_y = round - (pos_x - 31);
         alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;    // :1903, :1913: both still inside
         // the windows follow the band: seq1's moves up one field on a step down, seq2's down one field on a step right
-        {
+        constexpr unsigned kByteOnes = 0x01010101u;
+        unsigned match_lo[4], match_hi[4];                // bit 0 of byte j: a cell of the low / high half of the band matches
+        if constexpr (kCalm) {
+            // 2-bit fields, one 64-bit window per sequence: one shift each; "the characters differ" = z | z >> 1
+            const unsigned a_in = sa.next(), b_in = sb.next();
+            a2 = (a2 << (2u & dm)) | (a_in & dm);
+            b2 = (b2 >> (2u & rm)) | ((unsigned long long)(b_in & rm) << 62);
+            sa.used4 += 4 & dm;
+            sb.used4 += 4 & rm;
+            const unsigned long long z = a2 ^ b2;
+            const unsigned z_lo = (unsigned)z, z_hi = (unsigned)(z >> 32);
+            const unsigned same_lo = __builtin_amdgcn_bitop3_b32(z_lo, z_lo >> 1, 0u, 0x03);      // ~(a | b): bit 2c set = cell c matches
+            const unsigned same_hi = __builtin_amdgcn_bitop3_b32(z_hi, z_hi >> 1, 0u, 0x03);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {                 // byte j of phase p = cell 4j + p (low word) / 16 + 4j + p (high word)
+                match_lo[p] = (same_lo >> (2 * p)) & kByteOnes;
+                match_hi[p] = (same_hi >> (2 * p)) & kByteOnes;
+            }
+        } else {
             const unsigned a_in = sa.next(), b_in = sb.next();
             const unsigned shift_a = 4u & dm, shift_b = 4u & rm;
             const unsigned a_carry = (unsigned)(aw0 >> 60) & dm, b_carry = (unsigned)bw1 & 15u & rm;
@@ -675,17 +712,17 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
             bw1 = (bw1 >> shift_b) | ((unsigned long long)(b_in & rm) << 60);
             sa.used4 += 4 & dm;
             sb.used4 += 4 & rm;
-        }
-        // bit 4c of a word clear: its cell c is a match (three-bit codes: bit 0 of z | z >> 1 | z >> 2 = "they differ")
-        const unsigned long long z0 = aw0 ^ bw0, z1 = aw1 ^ bw1;
-        const unsigned long long d0 = z0 | (z0 >> 1) | (z0 >> 2), d1 = z1 | (z1 >> 1) | (z1 >> 2);
-        const unsigned dw[4] = {(unsigned)d0, (unsigned)(d0 >> 32), (unsigned)d1, (unsigned)(d1 >> 32)};        // cells 8w .. 8w + 7
-        constexpr unsigned kByteOnes = 0x01010101u;
-        unsigned even[4], odd[4];                         // bit 0 of byte j = cell 8w + 2j / 8w + 2j + 1 matches
+            // bit 4c of a word clear: its cell c is a match (three-bit codes: bit 0 of z | z >> 1 | z >> 2 = "they differ")
+            const unsigned long long z0 = aw0 ^ bw0, z1 = aw1 ^ bw1;
+            const unsigned long long d0 = z0 | (z0 >> 1) | (z0 >> 2), d1 = z1 | (z1 >> 1) | (z1 >> 2);
+            const unsigned dw[4] = {(unsigned)d0, (unsigned)(d0 >> 32), (unsigned)d1, (unsigned)(d1 >> 32)};    // cells 8w .. 8w + 7
+            // [2 (w & 1) + parity]: byte j = cell 8w + 2j + parity of the low (w < 2) / high half
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            even[w] = ~dw[w] & kByteOnes;
-            odd[w] = __builtin_amdgcn_bitop3_b32(dw[w] >> 4, kByteOnes, 0u, 0x0C);     // ~a & b in one (hipcc: v_not, shift, v_and)
+            for (int w = 0; w < 4; ++w) {
+                unsigned *dst = w < 2 ? match_lo : match_hi;
+                dst[2 * (w & 1)] = ~dw[w] & kByteOnes;
+                dst[2 * (w & 1) + 1] = __builtin_amdgcn_bitop3_b32(dw[w] >> 4, kByteOnes, 0u, 0x0C);       // ~a & b in one (hipcc: v_not, shift, v_and)
+            }
         }
         // S of cells (k, k + 16), k = 0 .. 16: left of register k is sv[k], up is sv[k + 1]; past the band's ends: dropped (0)
         unsigned sv[NV + 1];
@@ -711,9 +748,12 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const unsigned dsel = pick(rmask, sp[k + 1], sp[k]);              // diagonal (:1897 / :1908)
-            const unsigned j = (unsigned)(k & 7) >> 1;    // cell k = byte j of word k / 8, cell k + 16 = byte j of word k / 8 + 2
+            // where cell k's match byte lies (cell k + 16: the same place of match_hi): calm, phase k % 4 byte k / 4; exact,
+            // word k / 8 parity k % 2 byte (k % 8) / 2
+            const unsigned which = kCalm ? (unsigned)(k & 3) : 2u * ((unsigned)k >> 3) + ((unsigned)k & 1u);
+            const unsigned j = kCalm ? (unsigned)k >> 2 : (unsigned)(k & 7) >> 1;
             const unsigned sel = 0x000C000Cu | (j << 8) | ((4u + j) << 24);
-            const unsigned f = __builtin_amdgcn_perm(k & 1 ? odd[(k >> 3) + 2] : even[(k >> 3) + 2], k & 1 ? odd[k >> 3] : even[k >> 3], sel);
+            const unsigned f = __builtin_amdgcn_perm(match_hi[which], match_lo[which], sel);
             const unsigned vd = dsel + f + (both(k) + 0x00030003u + (unsigned)kScale * 0x10001u);     // dia + 3 / dia + 1, tag 3
             v[k] = sg_pk_max3(vd, vu[k], vl[k]);
             sp_next[k] = sv[k];
@@ -756,10 +796,8 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
             alive_m &= keep_opaque(-round_best) >> 31;    // alive && round_best != 0 (:1943-1946)
         }
         stage_codes[lane][round & 15] = make_uint2(tags_lo, tags_hi);
-        if ((round & 15) == 15) {                         // same place for every lane of the wavefront, every 16 rounds
+        if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4);
-            sa.top_up(kStreamStride);
-            sb.top_up(kStreamStride);
             if ((round & 31) == 31) {
                 if (real) *my_dirs = dir_word;
                 my_dirs += n;
@@ -773,6 +811,12 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
             for (int k = 0; k <= NV; ++k) sp_next[k] = sg_pk_sub_sat(sp_next[k], d2);
             off += delta;
         }
+        // the streams are topped up after round 0 (mod 16): a window of 8 rounds, which starts at 1 or 9 (mod 16), then finds
+        // all the characters it can consume in `sreg` (the calm test below looks at them)
+        if (K == 7 && (base & 8)) {
+            sa.top_up(kStreamStride);
+            sb.top_up(kStreamStride);
+        }
         last_round = round;
     };
 
@@ -782,47 +826,77 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     // a gap step adds 0), while the threshold climbs by one per round plus the rise of `best`, which is at most one per two
     // rounds (a diagonal step takes two) -- 12 in 8 rounds.  Those rounds then run without the X-drop test (one v_and per
     // register instead of compare, mask, apply) and without the guards for a dropped band maximum: the same results by
-    // construction, 14 % fewer instructions.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of
+    // construction, 15 % fewer instructions.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of
     // every alignment) or exact_only send the window down the exact path.  Two loops, one per kind of window, each running
     // for as long as its kind lasts: hipcc gives the two bodies different register assignments, and the ~180 moves between them
     // are paid only where the kind changes.
     constexpr int kCalmWindow = 8, kCalmMargin = kCalmWindow + kCalmWindow / 2 + 1;
-    static_assert((kMaxRound - 1) % 16 == 0 && 16 % kCalmWindow == 0, "whole windows");
-    auto window_kind = [&]() -> int {                     // 1 calm, 0 exact, -1 every alignment of the wavefront has ended
+    static_assert((kMaxRound - 1) % 16 == 0 && kCalmWindow == 8, "whole windows; one_round places the 16-round events by K and base");
+    // In this kernel a calm window also needs BASES ONLY -- in the band's windows now and among the at most 8 characters of
+    // either stream it will consume (no pad of the matrix's edges, no byte that was not 0..3): its rounds keep the sequence
+    // windows as 2 bits per cell, 64 bits per sequence, and shift, compare and spread half as many registers.
+    auto window_kind = [&](auto from_calm) -> int {       // 1 calm, 0 exact, -1 every alignment of the wavefront has ended
         if (!__any(alive_m != 0)) return -1;
         const unsigned low = sg_pk_min3(sg_pk_min3(sg_pk_min3(cur[0], cur[1], cur[2]), sg_pk_min3(cur[3], cur[4], cur[5]), sg_pk_min3(cur[6], cur[7], cur[8])),
                                         sg_pk_min3(sg_pk_min3(cur[9], cur[10], cur[11]), sg_pk_min3(cur[12], cur[13], cur[14]), cur[15]), cur[15]);
         const int low_stored = (int)min(low & 0xFFFFu, low >> 16) >> 7;
         const int thr_now = (best - kXDrop > 1 ? best - kXDrop : 1) - off;
-        const bool edgy = alive_m != 0 && low_stored < thr_now + kCalmMargin;
+        unsigned fields = (unsigned)(sa.sreg >> sa.used4) | (unsigned)(sb.sreg >> sb.used4);   // the next 8 characters of both streams
+        if constexpr (!decltype(from_calm)::value) {      // (the 2-bit windows of the calm loop hold bases by construction)
+            const unsigned long long w = aw0 | aw1 | bw0 | bw1;
+            fields |= (unsigned)w | (unsigned)(w >> 32);
+        }
+        const bool edgy = alive_m != 0 && (low_stored < thr_now + kCalmMargin || (fields & 0x44444444u) != 0);
         return !exact_only && !__any(edgy) ? 1 : 0;
     };
-    int round = 1, kind = window_kind();
+    // 16 fields of 4 bits (values 0..3) <-> 16 fields of 2 bits; only where the kind of window changes
+    auto squeeze2 = [](unsigned long long x) -> unsigned long long {
+        x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+        x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+        return (x | (x >> 16)) & 0xFFFFFFFFull;
+    };
+    auto spread2 = [](unsigned long long x) -> unsigned long long {
+        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+        x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+        return (x | (x << 2)) & 0x3333333333333333ull;
+    };
+    int round = 1, kind = window_kind(std::false_type());
     uint32_t calm_windows = 0;                            // (scalar: the loops are wavefront-uniform)
+#define SWMI_SG_WINDOW(CALM)                                                                                      \
+    one_round(CALM(), std::integral_constant<int, 0>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 1>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 2>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 3>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 4>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 5>(), round, sp_b, sp_a);                                        \
+    one_round(CALM(), std::integral_constant<int, 6>(), round, sp_a, sp_b);                                        \
+    one_round(CALM(), std::integral_constant<int, 7>(), round, sp_b, sp_a);                                        \
+    round += kCalmWindow
     while (kind >= 0) {
         if (kind == 1) {
+            a2 = squeeze2(aw0) | (squeeze2(aw1) << 32);
+            b2 = squeeze2(bw0) | (squeeze2(bw1) << 32);
+            __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) in the block that enters the loop: see the split sweep
             do {
-#pragma unroll
-                for (int k = 0; k < kCalmWindow; k += 2) {
-                    one_round(std::true_type(), round + k, sp_a, sp_b);
-                    one_round(std::true_type(), round + k + 1, sp_b, sp_a);
-                }
-                round += kCalmWindow;
+                SWMI_SG_WINDOW(std::true_type);
                 ++calm_windows;
-                kind = round < kMaxRound ? window_kind() : -1;
+                kind = round < kMaxRound ? window_kind(std::true_type()) : -1;
             } while (kind == 1);
+            aw0 = spread2(a2 & 0xFFFFFFFFull);
+            aw1 = spread2(a2 >> 32);
+            bw0 = spread2(b2 & 0xFFFFFFFFull);
+            bw1 = spread2(b2 >> 32);
         } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             do {
-#pragma unroll
-                for (int k = 0; k < kCalmWindow; k += 2) {
-                    one_round(std::false_type(), round + k, sp_a, sp_b);
-                    one_round(std::false_type(), round + k + 1, sp_b, sp_a);
-                }
-                round += kCalmWindow;
-                kind = round < kMaxRound ? window_kind() : -1;
+                SWMI_SG_WINDOW(std::false_type);
+                kind = round < kMaxRound ? window_kind(std::false_type()) : -1;
             } while (kind == 0);
         }
     }
+#undef SWMI_SG_WINDOW
     if (lane == 0) {                                      // windows run / of them calm, summed over the launch (swmi_semiglobal_window_stats)
         atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
         atomicAdd(&window_stats[1], calm_windows);
@@ -1201,25 +1275,44 @@ namespace {
 // mapping, one band cell per lane: the packed split sweep beats it down to a batch of ONE alignment, 9.5 against 10.2 ms,
 // profiles/r03_sg_small_batches.txt, and it is gone -- with it the second record format.)  The kernels
 // are compiled once per scheduling target W (amdgpu_waves_per_eu): hipcc orders the round for W resident wavefronts per
-// SIMD, and the version whose W matches what the batch actually puts on a SIMD wins by 20-40 %.
+// SIMD, and a build runs W wavefronts per SIMD at a time -- a batch that gives a SIMD fewer leaves SIMDs idle (the
+// dispatcher fills a SIMD to W before it moves on), one that gives it more runs in turns.
+//
+// Cost model, measured on 256 CUs with calm windows (profiles/r04_sg_kernel_matrix.txt, sweep phase in ms): a build runs
+// floor(w / W) full turns + one partial turn, w = wavefronts per SIMD the batch yields with that G.
+struct SweepBuild {
+    int id, lanes, waves;        // 10 G + W, G, W
+    float full;                  // one turn of W wavefronts per SIMD
+    float part[3];               // a last turn of 1 .. W - 1 wavefronts per SIMD
+};
+constexpr SweepBuild kSweepBuilds[] = {
+    {41, 4, 1, 7.75f, {0, 0, 0}},
+    {21, 2, 1, 10.3f, {0, 0, 0}},
+    {23, 2, 3, 25.3f, {17.5f, 17.5f, 0}},
+    {11, 1, 1, 15.7f, {0, 0, 0}},
+    {12, 1, 2, 26.5f, {13.5f, 0, 0}},            // (a batch of ONE wavefront per SIMD on this build: 26.8 -- never chosen: 11 is there)
+};
 int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
 {
     if (tuning.force_sweep >= 0) {
         const int s = tuning.force_sweep;
-        return s == 4 ? 44 : s == 2 ? 24 : s == 1 ? 13 : s;
+        return s == 4 ? 44 : s == 2 ? 23 : s == 1 ? 12 : s;
     }
-    // wavefronts per SIMD the batch yields with 4 / 2 / 1 lanes per alignment on THIS device (4 SIMDs per CU; a partitioned
-    // gfx950 reports fewer CUs).  Each mapping takes a fixed time per started wavefront-per-SIMD, measured on 256 CUs
-    // (profiles/r03_sg_kernel_matrix.txt, ms): fewer lanes per alignment = fewer instructions per alignment, but a SIMD
-    // with a single wavefront issues an instruction every ~6 cycles instead of every ~4.3.
-    const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;
-    const int w4 = (int)((n / 16 + simds - 1) / simds), w2 = (int)((n / 32 + simds - 1) / simds), w1 = (int)((n / 64 + simds - 1) / simds);
-    const double t4 = 3.6 + 6.2 * (w4 < 1 ? 1 : w4), t2 = 3.6 + 9.0 * (w2 < 1 ? 1 : w2), t1 = w1 <= 1 ? 20.4 : 3.7 + 16.05 * w1;
-    // the build whose scheduling target equals the wavefronts a SIMD actually gets (at most 4; the lane kernel's 145 registers
-    // fit three per SIMD)
-    if (t4 <= t2 && t4 <= t1) return 40 + (w4 < 1 ? 1 : w4 > 4 ? 4 : w4);
-    if (t2 <= t1) return 20 + (w2 < 1 ? 1 : w2 > 4 ? 4 : w2);
-    return 10 + (w1 < 1 ? 1 : w1 > 3 ? 3 : w1);
+    const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;     // (a partitioned gfx950 reports fewer CUs)
+    int best = 41;
+    float best_t = 0;
+    for (const SweepBuild &b : kSweepBuilds) {
+        const size_t wavefronts = (n * b.lanes + 63) / 64;
+        const int w = (int)((wavefronts + simds - 1) / simds);
+        const int turns = w / b.waves, rest = w % b.waves;
+        float t = turns * b.full + (rest ? b.part[rest - 1] : 0.0f);
+        if (b.id == 12 && w == 1) t = 26.8f;
+        if (best_t == 0 || t < best_t) {
+            best_t = t;
+            best = b.id;
+        }
+    }
+    return best;
 }
 inline int sweep_lanes(int sweep) { return sweep / 10; }
 }  // namespace
@@ -1279,10 +1372,8 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
         case 21: SWMI_SG_LAUNCH(2, 1, grid2); break;
         case 22: SWMI_SG_LAUNCH(2, 2, grid2); break;
         case 23: SWMI_SG_LAUNCH(2, 3, grid2); break;
-        case 24: SWMI_SG_LAUNCH(2, 4, grid2); break;
         case 11: SWMI_SG_LAUNCH1(1); break;
         case 12: SWMI_SG_LAUNCH1(2); break;
-        case 13: SWMI_SG_LAUNCH1(3); break;
         default: return hipErrorInvalidValue;
         }
 #undef SWMI_SG_LAUNCH

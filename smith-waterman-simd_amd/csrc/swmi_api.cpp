@@ -1149,9 +1149,9 @@ int swmi_semiglobal_xdrop_device(const void *d_seq1s, const void *d_seq2s, size_
 
 int swmi_semiglobal_set_mapping(int sweep)
 {
-    const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 13) ||
-                          (sweep >= 21 && sweep <= 24) || (sweep >= 41 && sweep <= 44);
-    if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..13, 21..24 or 41..44", sweep);
+    const bool sweep_ok = sweep == -1 || sweep == 1 || sweep == 2 || sweep == 4 || (sweep >= 11 && sweep <= 12) ||
+                          (sweep >= 21 && sweep <= 23) || (sweep >= 41 && sweep <= 44);
+    if (!sweep_ok) return fail(SWMI_ERR_INVALID_ARGUMENT, "sweep %d: -1, 1, 2, 4, 11..12, 21..23 or 41..44", sweep);
     // (the low half of the word; the high half is swmi_semiglobal_set_exact's)
     uint64_t was = sg_mapping_word().load(std::memory_order_relaxed);
     while (!sg_mapping_word().compare_exchange_weak(was, (was & ~uint64_t(0xffffffffu)) | uint64_t(uint32_t(sweep + 1)))) {}

@@ -98,7 +98,7 @@ while time.time() < t_end:
     for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
         cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
-    swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 24, 11, 12, 13)[sg_iter % 11])
+    swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 11, 12)[sg_iter % 9])
     sg_iter += 1
     if sg_iter % 2:                      # the entry that returns the walk's 2-bit moves, expanded on the host (round 4)
         scores, moves, lengths = swmi.semiglobal_xdrop_moves(a, b)

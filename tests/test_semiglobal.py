@@ -37,7 +37,7 @@ def sg_kernels(swmi_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep", [4, 2, 1, 41, 42, 43, 21, 22, 24, 11, 12, 13])
+@pytest.mark.parametrize("sweep", [4, 2, 1, 41, 42, 43, 44, 21, 22, 23, 11, 12])
 def test_gpu_semiglobal_matches_reference_fixtures(gpu, golden, sg_kernels, sweep):
     sg_kernels(sweep)
     f = golden("f6_semiglobal")
@@ -184,23 +184,24 @@ def test_gpu_semiglobal_scores_only(gpu, oracle, sg_kernels, sweep):
 @pytest.mark.gpu
 def test_gpu_semiglobal_mapping_choice_and_argument_check(gpu, swmi_mod):
     """swmi_semiglobal_kernels_for_batch reports what the launcher picks (band over 4 lanes for small batches,
-    2 lanes in between, one lane per alignment from 49152 on a 256-CU device); swmi_semiglobal_set_mapping rejects what is no
-    mapping and leaves the setting alone."""
+    2 lanes in between, one lane per alignment from 49152 on a 256-CU device -- except where a batch gives the SIMDs two and a
+    half or three wavefronts of 32 alignments); swmi_semiglobal_set_mapping rejects what is no mapping and leaves the setting alone."""
     if gpu.device_info()["compute_units"] == 256:
         want = {1: "sg_forward_split_kernel<4, 1>", 16384: "sg_forward_split_kernel<4, 1>", 32768: "sg_forward_split_kernel<2, 1>",
-                65536: "sg_forward_lane_kernel<1>", 98304: "sg_forward_split_kernel<2, 3>", 131072: "sg_forward_lane_kernel<2>",
-                262144: "sg_forward_lane_kernel<3>"}
+                49152: "sg_forward_lane_kernel<1>", 65536: "sg_forward_lane_kernel<1>", 81920: "sg_forward_split_kernel<2, 3>",
+                98304: "sg_forward_split_kernel<2, 3>", 131072: "sg_forward_lane_kernel<2>", 196608: "sg_forward_lane_kernel<2>",
+                262144: "sg_forward_lane_kernel<2>"}
         for n, name in want.items():
             assert swmi_mod.semiglobal_kernels_for_batch(n) == (name, "sg_walk_lane_kernel + sg_expand_kernel"), n
     swmi_mod.semiglobal_set_mapping(2)
     try:
-        assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 4>"
-        for bad in (0, 3, 5, 14, 20, 45, 101, 221):
+        assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 3>"
+        for bad in (0, 3, 5, 13, 14, 20, 24, 45, 101, 221):
             with pytest.raises(swmi_mod.SwmiError):
                 swmi_mod.semiglobal_set_mapping(bad)
-            assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 4>"      # unchanged
-        swmi_mod.semiglobal_set_mapping(13)
-        assert swmi_mod.semiglobal_kernels_for_batch(5)[0] == "sg_forward_lane_kernel<3>"
+            assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 3>"      # unchanged
+        swmi_mod.semiglobal_set_mapping(12)
+        assert swmi_mod.semiglobal_kernels_for_batch(5)[0] == "sg_forward_lane_kernel<2>"
     finally:
         swmi_mod.semiglobal_set_mapping(-1)
 
