@@ -302,16 +302,25 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
     uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 4);
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
-    auto flush_codes = [&](int g16) {                     // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
+    auto flush_codes = [&](int g16, auto together) {      // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 8 alignments x 128 B per store instruction, and NO branch between them: the rows of a ragged last block past
+        // alignment n - 1 hold that alignment's records once more (such lanes shadow it: same streams, same arithmetic) and
+        // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
+        // over; now the LDS reads go out together.
+        // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
+        uint4 v[A / 8];
+        if constexpr (decltype(together)::value) {
 #pragma unroll
-        for (int q = 0; q < A / 8; ++q) {                 // 8 alignments x 128 B per store instruction
-            const int fa = q * 8 + (lane >> 3), part = lane & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
-            if (block_first + fa < n)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + block_first + fa) * kCodeWindow + 2 * part) = v;
+            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+        }
+#pragma unroll
+        for (int q = 0; q < A / 8; ++q) {
+            if constexpr (!decltype(together)::value) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+            const uint32_t row = min(block_first + (uint32_t)(q * 8 + (lane >> 3)), n - 1);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + row) * kCodeWindow + 2 * (lane & 7)) = v[q];
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -509,7 +518,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
         }
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
-            flush_codes(round >> 4);
+            flush_codes(round >> 4, std::true_type());
             if ((round & 31) == 31) {
                 if (real && is_first) *my_dirs = dir_word;
                 my_dirs += n;
@@ -591,7 +600,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
         atomicAdd(&window_stats[1], calm_windows);
     }
-    if ((last_round & 15) != 15) flush_codes(last_round >> 4);
+    if ((last_round & 15) != 15) flush_codes(last_round >> 4, std::false_type());
     if (real && is_first) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
         summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
@@ -622,16 +631,25 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     constexpr size_t kStreamStride = 2 * A;
     const unsigned long long *stream_a = streams + (size_t)blockIdx.x * kStreamWords * kStreamStride + 2 * lane;
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
-    auto flush_codes = [&](int g16) {                     // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
+    auto flush_codes = [&](int g16, auto together) {      // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 8 alignments x 128 B per store instruction, and NO branch between them: the rows of a ragged last block past
+        // alignment n - 1 hold that alignment's records once more (such lanes shadow it: same streams, same arithmetic) and
+        // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
+        // over; now the LDS reads go out together.
+        // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
+        uint4 v[A / 8];
+        if constexpr (decltype(together)::value) {
 #pragma unroll
-        for (int q = 0; q < A / 8; ++q) {                 // 8 alignments x 128 B per store instruction
-            const int fa = q * 8 + (lane >> 3), part = lane & 7;
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage_codes[fa][2 * part]);
-            if (block_first + fa < n)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + block_first + fa) * kCodeWindow + 2 * part) = v;
+            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+        }
+#pragma unroll
+        for (int q = 0; q < A / 8; ++q) {
+            if constexpr (!decltype(together)::value) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+            const uint32_t row = min(block_first + (uint32_t)(q * 8 + (lane >> 3)), n - 1);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + row) * kCodeWindow + 2 * (lane & 7)) = v[q];
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -797,7 +815,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         }
         stage_codes[lane][round & 15] = make_uint2(tags_lo, tags_hi);
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
-            flush_codes(round >> 4);
+            flush_codes(round >> 4, std::true_type());
             if ((round & 31) == 31) {
                 if (real) *my_dirs = dir_word;
                 my_dirs += n;
@@ -901,7 +919,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         atomicAdd(&window_stats[0], (uint32_t)(round - 1) / kCalmWindow);
         atomicAdd(&window_stats[1], calm_windows);
     }
-    if ((last_round & 15) != 15) flush_codes(last_round >> 4);
+    if ((last_round & 15) != 15) flush_codes(last_round >> 4, std::false_type());
     if (real) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
         summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
