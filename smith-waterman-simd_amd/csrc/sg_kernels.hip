@@ -679,7 +679,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     sa.start(stream_a, kStreamStride, 31);
     sb.start(stream_a + 1, kStreamStride, 0);
     int pos_x = 31;
-    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
+    int best = kXDrop, best_round = 0, best_kmax = 31 << 2, best_px = 31, last_round = 0;
     int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     stage_codes[lane][0] = make_uint2(0, 0);
@@ -699,8 +699,12 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         const unsigned rm = (unsigned)rmask, dm = ~rm;
         pos_x -= rmask;
         dir_word = __builtin_amdgcn_alignbit(rm, dir_word, 1);
-        const int pos_y = round - (pos_x - 31);
-        alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;    // :1903, :1913: both still inside
+        // :1903, :1913: both still inside.  (Not asked in a calm round: every character such a window takes from the streams
+        // is a base, i.e. lies inside its sequence -- pos_y + 30 < kLen and pos_x - 32 < kLen after the step -- far from these limits.)
+        if constexpr (!kCalm) {
+            const int pos_y = round - (pos_x - 31);
+            alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;
+        }
         // the windows follow the band: seq1's moves up one field on a step down, seq2's down one field on a step right
         constexpr unsigned kByteOnes = 0x01010101u;
         unsigned match_lo[4], match_hi[4];                // bit 0 of byte j: a cell of the low / high half of the band matches
@@ -800,8 +804,10 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = (int)pick(imask, (unsigned)round_best, (unsigned)best);
         best_round = (int)pick(imask, (unsigned)round, (unsigned)best_round);
-        best_lane = (int)pick(imask, (unsigned)(kmax >> 2) & 31u, (unsigned)best_lane);  // highest cell among equals (:1957)
-        best_top = (int)pick(imask, (unsigned)pos_y, (unsigned)best_top);
+        // where: the winning value with its cell index (the highest cell among equals, :1957) and the band's column -- the cell
+        // and the row are taken out of them once, after the last round
+        best_kmax = (int)pick(imask, (unsigned)kmax, (unsigned)best_kmax);
+        best_px = (int)pick(imask, (unsigned)pos_x, (unsigned)best_px);
         const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941
         if constexpr (kCalm) {                            // every cell stays above the threshold
 #pragma unroll
@@ -922,7 +928,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     if ((last_round & 15) != 15) flush_codes(last_round >> 4, std::false_type());
     if (real) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
-        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
+        summary[a] = make_int4(best - kXDrop, best_round, (best_kmax >> 2) & 31, best_round - (best_px - 31));     // (pos_y = round - right steps)
     }
 }
 
@@ -1296,7 +1302,7 @@ namespace {
 // SIMD, and a build runs W wavefronts per SIMD at a time -- a batch that gives a SIMD fewer leaves SIMDs idle (the
 // dispatcher fills a SIMD to W before it moves on), one that gives it more runs in turns.
 //
-// Cost model, measured on 256 CUs with calm windows (profiles/r04_sg_kernel_matrix.txt, sweep phase in ms): a build runs
+// Cost model, measured on 256 CUs on SpeedtestSemiGlobal inputs, i.e. calm windows (profiles/r04_sg_kernel_matrix.txt, sweep phase in ms): a build runs
 // floor(w / W) full turns + one partial turn, w = wavefronts per SIMD the batch yields with that G.
 struct SweepBuild {
     int id, lanes, waves;        // 10 G + W, G, W
@@ -1304,11 +1310,11 @@ struct SweepBuild {
     float part[3];               // a last turn of 1 .. W - 1 wavefronts per SIMD
 };
 constexpr SweepBuild kSweepBuilds[] = {
-    {41, 4, 1, 7.75f, {0, 0, 0}},
-    {21, 2, 1, 10.3f, {0, 0, 0}},
-    {23, 2, 3, 25.3f, {17.5f, 17.5f, 0}},
-    {11, 1, 1, 15.7f, {0, 0, 0}},
-    {12, 1, 2, 26.5f, {13.5f, 0, 0}},            // (a batch of ONE wavefront per SIMD on this build: 26.8 -- never chosen: 11 is there)
+    {41, 4, 1, 7.7f, {0, 0, 0}},
+    {21, 2, 1, 10.0f, {0, 0, 0}},
+    {23, 2, 3, 25.7f, {17.6f, 17.6f, 0}},
+    {11, 1, 1, 15.3f, {0, 0, 0}},
+    {12, 1, 2, 26.7f, {13.0f, 0, 0}},            // (a batch of ONE wavefront per SIMD on this build: 26.6 -- never chosen: 11 is there)
 };
 int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
 {
@@ -1324,7 +1330,7 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
         const int w = (int)((wavefronts + simds - 1) / simds);
         const int turns = w / b.waves, rest = w % b.waves;
         float t = turns * b.full + (rest ? b.part[rest - 1] : 0.0f);
-        if (b.id == 12 && w == 1) t = 26.8f;
+        if (b.id == 12 && w == 1) t = 26.6f;
         if (best_t == 0 || t < best_t) {
             best_t = t;
             best = b.id;
