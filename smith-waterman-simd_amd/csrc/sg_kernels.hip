@@ -373,7 +373,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         }
     }
     int pos_x = 31;
-    int best = kXDrop, best_round = 0, best_lane = 31, best_top = 0, last_round = 0;
+    int best = kXDrop, best_round = 0, best_kmax = 31 << 2, best_px = 31, last_round = 0;
     int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
     if (is_first) stage_codes[al][0] = make_uint2(0, 0);
@@ -499,8 +499,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const int imask = alive_m & (keep_opaque(best - round_best) >> 31);  // improved = alive && round_best > best (:1933-1936)
         best = pick(imask, round_best, best);
         best_round = pick(imask, round, best_round);
-        best_lane = pick(imask, (kmax >> 2) & 31, best_lane);                 // highest cell among equals: where the search of :1957 stops
-        best_top = pick(imask, pos_y, best_top);
+        // where: the winning value with its cell index (the highest cell among equals: where the search of :1957 stops) and the
+        // band's column -- the cell and the row are taken out of them once, after the last round
+        best_kmax = pick(imask, kmax, best_kmax);
+        best_px = pick(imask, pos_x, best_px);
         const int thr_true = best - kXDrop > 1 ? best - kXDrop : 1;           // :1938-1941, and "0 means dropped"
         if constexpr (kCalm) {
 #pragma unroll
@@ -603,7 +605,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     if ((last_round & 15) != 15) flush_codes(last_round >> 4, std::false_type());
     if (real && is_first) {
         if ((last_round & 31) != 31) *my_dirs = dir_word >> (31 - (last_round & 31));
-        summary[a] = make_int4(best - kXDrop, best_round, best_lane, best_top);
+        summary[a] = make_int4(best - kXDrop, best_round, (best_kmax >> 2) & 31, best_round - (best_px - 31));     // (pos_y = round - right steps)
     }
 }
 

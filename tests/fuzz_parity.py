@@ -98,6 +98,11 @@ while time.time() < t_end:
     for k in range(0, m, 7):             # indels: shift a tail of some sequences by a few bases
         cut = int(rng.integers(100, 16000)); sh = int(rng.integers(1, 40))
         b[k, cut:] = np.roll(b[k], sh)[cut:]
+    for k in range(3, m, 5):             # runs of guaranteed mismatches around the X-drop limit of 70: some alignments die there, some
+        for _ in range(int(rng.integers(1, 5))):        # scrape past -- cells at the threshold, dropped cells, dead lanes beside live ones
+            lo = int(rng.integers(50, 16200)); run = int(rng.integers(30, 111))
+            b[k, lo: lo + run] = (a[k, lo: lo + run] + 1 + (rng.integers(0, 3, len(a[k, lo: lo + run])) if rng.random() < 0.5 else 0)) & 3
+    swmi.semiglobal_set_exact(sg_iter % 5 == 4)          # every fifth batch on the exact path only (no calm windows)
     swmi.semiglobal_set_mapping((41, 42, 43, 44, 21, 22, 23, 11, 12)[sg_iter % 9])
     sg_iter += 1
     if sg_iter % 2:                      # the entry that returns the walk's 2-bit moves, expanded on the host (round 4)
@@ -109,6 +114,7 @@ while time.time() < t_end:
         ok = list(ex.map(check, [(a[k], b[k], int(scores[k]), tbs[k]) for k in range(m)]))
     sg_total += m; sg_bad += m - sum(ok)
     print("... semi-global %d alignments, %d mismatches" % (sg_total, sg_bad), flush=True)
+swmi.semiglobal_set_exact(False)
 print("semi-global fuzz vs %s: %d alignments (score + full traceback; positions entry and moves entry + host expansion in turn), %d mismatches" % ("reference simd_mark4" if ref else "oracle", sg_total, sg_bad), flush=True)
 
 # ---- banded affine extension vs oracle/sw_oracle.c (no reference counterpart: parity unpinned by the reference) ----
