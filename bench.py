@@ -182,6 +182,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="N = 1: headline only (profiling passes use this)")
+    ap.add_argument("--sg-plain", action="store_true", help="semi-global mode: the timed calls only -- no exact-path and two-streams "
+                    "legs (the counter passes use this: their per-kernel averages then cover one kind of launch)")
     ap.add_argument("--sustained-seconds", type=float, default=2.5)
     ap.add_argument("--force-dist", action="store_true", help="create the process group and run the score gather even "
                     "with one rank (rehearses the RCCL path on a one-GPU box)")
@@ -456,12 +458,12 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     per_wave, marker = sg_sweep_shape(name)
     # Two loops of eight unrolled rounds each: the exact one (X-drop test: the marker) and the calm one (sg_kernels.hip: windows in
     # which no cell can reach the threshold); the library counts how many windows of the last call were calm.  The record
-    # flush + stream top-up block runs on every 16th round and hipcc keeps one copy behind each of a loop's eight rounds, so of
-    # the conditional instructions the census finds in a trip 1/16 run on average.
+    # flush and the stream top-up each sit behind ONE of a loop's eight rounds under a test of the window's number: they run on
+    # every second trip.
     windows, calm_windows = swmi.semiglobal_window_stats(stream.cuda_stream)
     calm_share = calm_windows / windows if windows else 0.0
     roof = issue_bound("^" + name + "$", rounds * (1.0 - calm_share), (P + per_wave - 1) // per_wave, sweep_ms, marker=marker,
-                       conditional_share=1.0 / 16, pick="most",
+                       conditional_share=0.5, pick="most",
                        second={"marker": ("v_pk_maximum3_f16", marker[1] * 3 // 2), "exclude": marker[0], "trips": rounds * calm_share})
     roof["calm_window_share"] = round(calm_share, 4)
     traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
@@ -478,21 +480,22 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     line["roofline"] = roof
     # the same call with every round on the exact path (what a batch of alignments that hover at their X-drop thresholds runs)
     forced = os.environ.get("SWMI_SG_EXACT") == "1"
-    swmi.semiglobal_set_exact(True)
-    try:
-        ph = [swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap,
-                                          lengths.data_ptr(), stream.cuda_stream) for _ in range(3)]
-    finally:
-        swmi.semiglobal_set_exact(forced)
-    ex_sweep, ex_tb = sum(p[0] for p in ph) / 3, sum(p[1] for p in ph) / 3
-    line["exact_path_forced"] = {"sweep_ms": round(ex_sweep, 3), "traceback_ms": round(ex_tb, 3),
-                                 "value": round(P / ((ex_sweep + ex_tb) * 1e-3), 1), "unit": "alignments/s",
-                                 "note": "swmi_semiglobal_set_exact(1): no calm windows, the X-drop test in every round; same results"}
+    if not getattr(args, "sg_plain", False):
+        swmi.semiglobal_set_exact(True)
+        try:
+            ph = [swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), P, scores.data_ptr(), tb.data_ptr(), cap,
+                                              lengths.data_ptr(), stream.cuda_stream) for _ in range(3)]
+        finally:
+            swmi.semiglobal_set_exact(forced)
+        ex_sweep, ex_tb = sum(p[0] for p in ph) / 3, sum(p[1] for p in ph) / 3
+        line["exact_path_forced"] = {"sweep_ms": round(ex_sweep, 3), "traceback_ms": round(ex_tb, 3),
+                                     "value": round(P / ((ex_sweep + ex_tb) * 1e-3), 1), "unit": "alignments/s",
+                                     "note": "swmi_semiglobal_set_exact(1): no calm windows, the X-drop test in every round; same results"}
     # Two calls in flight on two streams (the library keeps a workspace per stream: tests/test_gpu_multi.py): the second
     # call's sweep shares the SIMDs with the first one's -- two wavefronts per SIMD issue 2 instructions per ~4.5 cycles where
     # one issues 1 per ~5 -- and the tracebacks run under the other call's sweep.  Same per-call batch, same results; a
     # separate figure, never the row's `value` (which is one call at a time).
-    if P * 2 * (2 * L + cap * 8 + 16) < 200e9:
+    if P * 2 * (2 * L + cap * 8 + 16) < 200e9 and not getattr(args, "sg_plain", False):
         s2 = torch.cuda.Stream()
         d1b, d2b = d1.clone(), d2.clone()
         scores_b, lengths_b = torch.empty_like(scores), torch.empty_like(lengths)
@@ -604,6 +607,10 @@ def row_summary(line):
         out["host_buffer_path"] = line["host_buffer_path"]
     if line.get("two_calls_in_flight"):
         out["two_calls_in_flight"] = line["two_calls_in_flight"]
+    if line.get("exact_path_forced"):
+        out["exact_path_forced"] = line["exact_path_forced"]
+    if r.get("calm_window_share") is not None:
+        out["calm_window_share"] = r["calm_window_share"]
     return out
 
 
