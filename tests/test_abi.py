@@ -26,7 +26,8 @@ def test_header_declares_the_expected_surface():
                  "swmi_init_all", "swmi_init_devices", "swmi_use_gpu", "swmi_num_gpus", "swmi_shard_bounds",
                  "swmi_score_batch_multi", "swmi_score_batch_packed_multi", "swmi_sharded_create", "swmi_sharded_score",
                  "swmi_sharded_wait", "swmi_sharded_scores_host", "swmi_sharded_gathered_device", "swmi_sharded_time",
-                 "swmi_sharded_destroy", "swmi_semiglobal_kernels_for_batch", "swmi_semiglobal_release_workspaces"):
+                 "swmi_sharded_destroy", "swmi_semiglobal_kernels_for_batch", "swmi_semiglobal_release_workspaces",
+                 "swmi_semiglobal_set_mapping", "swmi_semiglobal_set_exact", "swmi_semiglobal_window_stats"):
         assert must in syms
 
 
@@ -62,6 +63,16 @@ def test_argument_errors_do_not_need_a_device(swmi_mod):
     assert lib.swmi_score_batch(None, a.ctypes.data, 1, sm.ctypes.data, 15, out.ctypes.data) == swmi_mod.ERR_INVALID_ARGUMENT
     assert lib.swmi_set_schedule(3, 0) == swmi_mod.ERR_INVALID_ARGUMENT
     assert lib.swmi_set_schedule(8, 0) == swmi_mod.OK
+    # the semi-global switches: a mapping that does not exist (13 and 24 went with their spilling builds), an exact flag that is no flag
+    for bad in (0, 3, 13, 24, 45):
+        assert lib.swmi_semiglobal_set_mapping(bad) == swmi_mod.ERR_INVALID_ARGUMENT
+    for ok in (12, 23, 44, 1, 2, 4, -1):
+        assert lib.swmi_semiglobal_set_mapping(ok) == swmi_mod.OK
+    assert lib.swmi_semiglobal_set_exact(2) == swmi_mod.ERR_INVALID_ARGUMENT and lib.swmi_semiglobal_set_exact(-1) == swmi_mod.ERR_INVALID_ARGUMENT
+    assert lib.swmi_semiglobal_set_exact(1) == swmi_mod.OK and lib.swmi_semiglobal_set_exact(0) == swmi_mod.OK
+    counts = (ctypes.c_uint64 * 2)(7, 7)
+    assert lib.swmi_semiglobal_window_stats(None, None) == swmi_mod.ERR_INVALID_ARGUMENT
+    assert lib.swmi_semiglobal_window_stats(None, counts) != swmi_mod.OK and list(counts) == [0, 0]       # no device: refused, counters zeroed
 
 
 def test_c_shard_rule_is_the_python_shard_rule(swmi_mod):
