@@ -340,7 +340,7 @@ def test_gpu_semiglobal_mapping_survives_a_reinit(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sweep", [41, 21, 11])
-def test_gpu_semiglobal_calm_windows_change_nothing(gpu, sg_kernels, sweep):
+def test_gpu_semiglobal_calm_windows_change_nothing(gpu, oracle, sg_kernels, sweep):
     """The sweeps skip the X-drop test in windows of 8 rounds in which no band cell can reach the threshold (sg_kernels.hip,
     "CALM WINDOWS"); swmi_semiglobal_set_exact(1) sends every window down the exact path.  Same scores, lengths and moves
     either way -- on healthy alignments (nearly every window calm), on alignments that die by the X-drop rule and on a batch
@@ -395,3 +395,10 @@ def test_gpu_semiglobal_calm_windows_change_nothing(gpu, sg_kernels, sweep):
     assert c3 == 0 and 0 < c2 < w2
     assert np.array_equal(s2, s3) and np.array_equal(l2, l3) and all(np.array_equal(x, y) for x, y in zip(m2, m3))
     assert int(l2.min()) < 16384 < int(l2.max())
+    # ... and both are the oracle's (pinned to the reference by fixture F6): alignments that die, that scrape past, healthy ones
+    for k in list(range(0, 24)) + [n - 1]:
+        want_score, want_tb = oracle.semiglobal(a2[k], bad[k])
+        assert int(s2[k]) == want_score and int(l2[k]) == len(want_tb), k
+        words = np.zeros(gpu.SG_MOVE_WORDS, np.uint64)
+        words[: len(m2[k])] = m2[k].view(np.uint64)
+        assert np.array_equal(gpu.semiglobal_expand_moves(words, int(l2[k])), want_tb), k
