@@ -142,3 +142,63 @@ int sg_oracle_xdrop(const uint8_t *seq1, const uint8_t *seq2, int32_t *score, in
     free(tmp); free(t.cell); free(t.top_y);
     return 0;
 }
+
+/* The invariant behind the GPU sweeps' "calm windows" (smith-waterman-simd_amd/csrc/sg_kernels.hip), checked on the reference's
+ * own recurrence (:1895-1946) -- test infrastructure like everything here.  At the start of every window of `window` rounds
+ * (rounds 1, 1 + window, ...) the band is called calm when none of its 32 cells is dropped and the lowest one lies at least
+ * `margin` above the X-drop threshold best - 70.  The claim: inside a calm window the X-drop rule drops nothing (so the GPU may
+ * skip the test there), for margin >= window + window / 2 + 1.  counts[0] = windows, counts[1] = calm windows, counts[2] =
+ * cells the rule dropped inside calm windows (the claim: 0).  Returns 0. */
+int sg_oracle_calm_windows(const uint8_t *seq1, const uint8_t *seq2, int window, int margin, long counts[3])
+{
+    int cur[SG_BAND], hor[SG_BAND], ver[SG_BAND], dia[SG_BAND];
+    long pos_y = 0, pos_x = 31;
+    int best = SG_X, round, calm = 0;
+    memset(cur, 0, sizeof cur); memset(hor, 0, sizeof hor); memset(ver, 0, sizeof ver); memset(dia, 0, sizeof dia);
+    cur[31] = SG_X;
+    counts[0] = counts[1] = counts[2] = 0;
+    for (round = 1; round < SG_MAX_ROUND; ++round) {
+        if ((round - 1) % window == 0) {
+            int low = cur[0];
+            for (int k = 1; k < SG_BAND; ++k) if (cur[k] < low) low = cur[k];
+            calm = low != 0 && low - (best - SG_X) >= margin;
+            ++counts[0];
+            counts[1] += calm;
+        }
+        if (cur[0] < cur[31]) {
+            for (int k = 0; k < SG_BAND; ++k) dia[k] = ver[k];
+            for (int k = 0; k < SG_BAND; ++k) hor[k] = cur[k];
+            for (int k = 0; k < SG_BAND - 1; ++k) ver[k] = cur[k + 1];
+            ver[31] = 0;
+            if (++pos_x > 32 + SG_LEN + 31) break;
+        } else {
+            for (int k = 0; k < SG_BAND; ++k) dia[k] = hor[k];
+            for (int k = 0; k < SG_BAND; ++k) ver[k] = cur[k];
+            for (int k = SG_BAND - 1; k > 0; --k) hor[k] = cur[k - 1];
+            hor[0] = 0;
+            if (++pos_y > 1 + SG_LEN) break;
+        }
+        int round_best = 0;
+        for (int k = 0; k < SG_BAND; ++k) {
+            const long y = pos_y + 31 - k, x = pos_x - 62 + k;
+            const int c1 = sg_base1(seq1, y), c2 = sg_base2(seq2, x);
+            const int s = (c1 < 4 && c2 < 4 && c1 == c2) ? 1 : -1;
+            int v = 0;
+            if (dia[k] != 0 && dia[k] + s > v) v = dia[k] + s;
+            if (hor[k] != 0 && hor[k] - 1 > v) v = hor[k] - 1;
+            if (ver[k] != 0 && ver[k] - 1 > v) v = ver[k] - 1;
+            cur[k] = v;
+            if (v > round_best) round_best = v;
+        }
+        if (round_best > best) best = round_best;
+        for (int k = 0; k < SG_BAND; ++k) {
+            if (cur[k] < best - SG_X) {
+                if (calm) ++counts[2];                 /* (a cell that is 0 already counts too: nothing may be dropped here) */
+                cur[k] = 0;
+            }
+        }
+        if (round_best == 0) break;
+    }
+    return 0;
+}
+

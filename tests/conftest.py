@@ -77,6 +77,14 @@ class Oracle:
         assert rc == 0, "sg_oracle_xdrop failed (%d)" % rc
         return score.value, tb[: ln.value].copy()
 
+    def calm_windows(self, seq1, seq2, window=8, margin=13):
+        """(windows, calm windows, cells dropped inside calm windows) of oracle/sg_oracle.c's sg_oracle_calm_windows."""
+        a = np.ascontiguousarray(seq1, np.uint8)
+        b = np.ascontiguousarray(seq2, np.uint8)
+        counts = (ctypes.c_long * 3)()
+        assert self.lib.sg_oracle_calm_windows(self._p(a), self._p(b), int(window), int(margin), counts) == 0
+        return int(counts[0]), int(counts[1]), int(counts[2])
+
     def generate(self, n, seed, first_pair=0):
         a = np.zeros((n, 128), np.uint8)
         b = np.zeros((n, 128), np.uint8)

@@ -28,6 +28,48 @@ def test_oracle_reproduces_the_reference_results(oracle, golden):
         assert tuple(tb[-1]) == tuple(f["ends"][k])
 
 
+def test_calm_window_invariant_on_the_reference_recurrence(oracle, golden):
+    """The GPU sweeps skip the X-drop test in windows of 8 rounds that start with every band cell alive and at least 13 above
+    the threshold (sg_kernels.hip, "CALM WINDOWS").  The claim behind it -- inside such a window the rule of source.cpp:1938-1941
+    drops nothing -- is checked here on the CPU restatement of the reference's recurrence, for the fixture's inputs, for
+    substitution-only relatives (nearly every window calm) and for inputs built to graze the threshold; and the condition
+    has teeth: with a margin of 1 instead of 13 the same inputs DO drop cells inside 'calm' windows."""
+    f = golden("f6_semiglobal")
+    rng = np.random.default_rng(813)
+    cases = [(f["seq1"][k], f["seq2"][k]) for k in range(len(f["scores"]))]
+    for p_sub in (0.0, 0.05, 0.15, 0.3):
+        a = rng.integers(0, 4, 16384, dtype=np.uint8)
+        b = np.where(rng.random(16384) < p_sub, rng.integers(0, 4, 16384, dtype=np.uint8), a).astype(np.uint8)
+        cases.append((a, b))
+    for k in range(24):                          # runs of guaranteed mismatches of 40 .. 100 around the X-drop limit of 70, and gaps
+        a = rng.integers(0, 4, 16384, dtype=np.uint8)
+        b = a.copy()
+        for _ in range(1 + k % 6):
+            lo, run = int(rng.integers(100, 16000)), int(rng.integers(40, 101))
+            b[lo: lo + run] = (a[lo: lo + run] + 1) & 3
+        if k % 3 == 0:
+            cut, sh = int(rng.integers(100, 16000)), int(rng.integers(1, 30))
+            b[cut:] = np.roll(b, sh)[cut:]
+        cases.append((a, b))
+    for run in (45, 50, 60, 69, 70, 71, 80):     # stretches without a match at any offset: the whole band sinks towards the threshold
+        a = rng.integers(0, 4, 16384, dtype=np.uint8)
+        b = a.copy()
+        for lo in (3000, 8000, 12000):
+            a[lo: lo + run], b[lo: lo + run] = 0, 1
+        cases.append((a, b))
+    calm_total = grazed = 0
+    for a, b in cases:
+        windows, calm, dropped = oracle.calm_windows(a, b, 8, 13)
+        assert dropped == 0 and 0 < windows <= 4096 and calm <= windows
+        calm_total += calm
+        for window, margin in ((8, 12 + 1), (16, 24 + 1), (4, 6 + 1)):                  # margin = window + window / 2 + 1 for other windows too
+            assert oracle.calm_windows(a, b, window, margin)[2] == 0
+        grazed += oracle.calm_windows(a, b, 8, 1)[2]
+    assert calm_total > 2000 * 4                 # the substitution-only relatives alone: > 90 % of their 4096 windows
+    assert oracle.calm_windows(cases[17][0], cases[17][1], 8, 13)[1] > 3700      # (5 % substitutions: SpeedtestSemiGlobal's inputs)
+    assert grazed > 0                            # "every cell alive" alone is not enough: with a margin of 1 cells ARE dropped inside windows
+
+
 @pytest.fixture
 def sg_kernels(swmi_mod):
     """Select the sweep mapping (4 / 2 / 1 = band over 4 / 2 lanes / in one lane, 10 * lanes + W = a scheduling target)
