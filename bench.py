@@ -887,9 +887,10 @@ def single_gpu(args, swmi, np, torch, local_rank):
     int32_row("fixed_111_scorer_int32_cell_kernel", 1, -1, 1, ms111, "sm +1/-1, gap 1 on the int32 kernel")
     del d1, d2, scores
     torch.cuda.empty_cache()
-    rows["banded_affine_1024"] = row_summary(bench_banded(args, swmi, np, torch, local_rank, steps=10, warmup=3))
+    # (the clock takes ~10 launches to settle on a new kernel: with 3 warm-up launches this row read 6 % low)
+    rows["banded_affine_1024"] = row_summary(bench_banded(args, swmi, np, torch, local_rank, steps=30, warmup=12))
     torch.cuda.empty_cache()
-    rows["semiglobal_xdrop_65536"] = row_summary(bench_semiglobal(args, swmi, np, torch, local_rank, steps=3, warmup=1))
+    rows["semiglobal_xdrop_65536"] = row_summary(bench_semiglobal(args, swmi, np, torch, local_rank, steps=5, warmup=2))
     line["rows"] = rows
     return line
 
