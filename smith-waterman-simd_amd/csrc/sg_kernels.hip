@@ -11,6 +11,8 @@
 //     the traceback needs: a 2-bit predecessor TAG per cell (3 diagonal / 2 up / 1 left: the candidate that won the cell's
 //     max, in the reference's own tie-break order :1962-1971) = 8 bytes, and ONE bit for the band's move (right / down);
 //     the row of the band's top cell is rebuilt from the move bits (round - right moves so far = a popcount).
+//     The X-drop rule (:1938-1941) is not asked in windows of 8 rounds in which no cell can reach the threshold ("CALM
+//     WINDOWS" in the kernels: a margin argument, the same results) -- two loops per kernel, exact and calm.
 //   * traceback: follows the codes from the best cell back to (0,0) and returns the positions in ascending order, as the
 //     reference does (:1951-1975): one lane per walk that records its moves (sg_walk_lane_kernel) + a prefix-sum kernel
 //     that expands them into positions (sg_expand_kernel).
