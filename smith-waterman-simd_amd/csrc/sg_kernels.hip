@@ -28,31 +28,30 @@ namespace {
 constexpr int kLen = 16384;                 // std::array<uint8_t,16384>, source.cpp:1837-1838
 constexpr int kXDrop = 70;                  // X_THRESHOLD, source.cpp:1848
 constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
-// Predecessor records: 8 bytes per alignment and round, WINDOW-MAJOR: 16 rounds of one alignment = one 128-byte line, and the
-// lines of one window lie side by side for all alignments of the batch:
-//     record of (alignment a, round r) = uint2 index ((r / 16) * n + a) * 16 + (r % 16)
+// Predecessor records: 8 bytes per alignment and round (band cell k's 2-bit tag: below), WINDOW-MAJOR and in TWO HALVES:
+//     centre half = cells 8 .. 23 (cell 8 + k at bits 2k of a 32-bit word), outer half = cells 0 .. 7 (low 16 bits) and
+//     24 .. 31 (high 16 bits); 16 rounds of one alignment = one 64-byte piece per half, and the pieces of one window lie side
+//     by side for all alignments of the batch:
+//         centre word of (alignment a, round r) = uint32 index ((r / 16) * n + a) * 16 + (r % 16) of the centre array,
+//         the outer word the same index of the outer array behind it.
+// A walk that stays in cells 8 .. 23 -- where the band keeps the best path -- never needs the outer half: the walk kernel
+// fetches the centre pieces only (half the bytes of the records) and the outer piece of a window when a walk of its
+// wavefront leaves the centre in it.  (Round 4; before, a round's record was one 8-byte word and a window one 128-byte line.)
 // Sweeps and walks move through the rounds in lockstep -- every alignment of a wavefront is in the same window at the same
-// time -- so a sweep wavefront's flush (its 16 / 32 / 64 alignments) and a walk wavefront's fetch (its 64 walks) are ONE
-// contiguous block of 2 .. 8 KB, written and read with fully coalesced 16-byte accesses.  (Round 2 kept one array per alignment: a walk
+// time -- so a sweep wavefront's flush (its 16 / 32 / 64 alignments) and a walk wavefront's fetch (its 64 walks) are
+// contiguous blocks of 1 .. 4 KB per half, written and read with fully coalesced 16-byte accesses.  (Round 2 kept one array per alignment: a walk
 // wavefront's fetch was 64 separate lines 262 KB apart, each requested in 16-byte pieces by one lane: 3.5 TB/s.)
-constexpr int kCodeWindow = 16;                           // rounds per line
+constexpr int kCodeWindow = 16;                           // rounds per piece
 constexpr int kCodeWindows = (kMaxRound + kCodeWindow - 1) / kCodeWindow;
-__device__ __forceinline__ size_t code_index(uint32_t n, uint32_t a, int round)          // in uint2 (one round's record)
-{
-    return ((size_t)(round / kCodeWindow) * n + a) * kCodeWindow + (round % kCodeWindow);
-}
+constexpr int kHalfQuads = kCodeWindow / 4;               // uint4 per piece (64 bytes)
+__device__ __forceinline__ size_t half_quads(uint32_t n) { return (size_t)kCodeWindows * n * kHalfQuads; }   // uint4 per half array
 // move bits: bit (r & 31) of word r >> 5 = 1 when the band stepped right in round r (source.cpp:1895); stored
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
 constexpr int kDirWords = kMaxRound / 32 + 1;
 // Predecessor records.  Every sweep stores, per round and band cell, the 2-bit TAG of the candidate that won the cell's
 // three-way max: 3 diagonal, 2 up, 1 left (0: round 0 / nothing) -- the reference's tie-break order (source.cpp:1962-1971)
-// falls out of comparing equal values by tag -- band cell k at bits 2k..2k+1 of the round's 64 bits.
+// falls out of comparing equal values by tag -- band cell k at bits 2k..2k+1 of the round's 64 bits, which leave as two words (above).
 // The walk hands the tags on as its moves; the expand kernel reads a row step off bit 1 and a column step off bit 0.
-__device__ __forceinline__ unsigned record_tag(uint2 cw, int bl)
-{
-    return (unsigned)((((unsigned long long)cw.y << 32) | cw.x) >> (2 * bl)) & 3u;
-}
-
 // max over each row of 16 lanes, left in every lane of the row: four DPP butterflies (v_max_i32_dpp, no LDS crossbar)
 __device__ __forceinline__ int row16_max(int v)
 {
@@ -302,27 +301,40 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const unsigned long long *stream_a = streams + (size_t)blockIdx.x * kStreamWords * kStreamStride + 2 * al;
     const unsigned long long *stream_b = stream_a + 1;
     // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
-    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]) + g * (C / 4);
+    // (a staged record = centre word, cells 8 .. 23, then outer word, cells 0 .. 7 | 24 .. 31: byte offsets 0 and 4).  The
+    // lane's cells in 16-bit pieces of 8: piece j of the band goes to offset 4, 0, 2, 6 for j = 0 .. 3
+    const int piece0 = g * C / 8;                         // first piece of this lane (C / 8 pieces: 1 or 2)
+    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]);
+    const int off_a = piece0 == 0 ? 4 : piece0 == 1 ? 0 : piece0 == 2 ? 2 : 6;
+    const int off_b = piece0 + 1 == 1 ? 0 : 6;            // (C = 16: the lane's second piece is piece 1 or 3)
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
     auto flush_codes = [&](int g16, auto together) {      // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 8 alignments x 128 B per store instruction, and NO branch between them: the rows of a ragged last block past
+        // NO branch between the stores: the rows of a ragged last block past
         // alignment n - 1 hold that alignment's records once more (such lanes shadow it: same streams, same arithmetic) and
         // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
         // over; now the LDS reads go out together.
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
+        // a staged round is (centre word, outer word); four lanes take one alignment's 16 rounds, four rounds each, and part
+        // them: 16 alignments x 64 B of centre words, then of outer words, per pair of store instructions
         uint4 v[A / 8];
         if constexpr (decltype(together)::value) {
 #pragma unroll
-            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[(q / 2) * 16 + (lane >> 2)][4 * (lane & 3) + 2 * (q & 1)]);
         }
+        uint4 *centre = reinterpret_cast<uint4 *>(codes), *outer = centre + half_quads(n);
 #pragma unroll
-        for (int q = 0; q < A / 8; ++q) {
-            if constexpr (!decltype(together)::value) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
-            const uint32_t row = min(block_first + (uint32_t)(q * 8 + (lane >> 3)), n - 1);
-            *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + row) * kCodeWindow + 2 * (lane & 7)) = v[q];
+        for (int q = 0; q < A / 16; ++q) {
+            if constexpr (!decltype(together)::value) {
+                v[2 * q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3)]);
+                v[2 * q + 1] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3) + 2]);
+            }
+            const uint32_t row = min(block_first + (uint32_t)(q * 16 + (lane >> 2)), n - 1);
+            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + (lane & 3);
+            centre[at] = make_uint4(v[2 * q].x, v[2 * q].z, v[2 * q + 1].x, v[2 * q + 1].z);
+            outer[at] = make_uint4(v[2 * q].y, v[2 * q].w, v[2 * q + 1].y, v[2 * q + 1].w);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -515,11 +527,11 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
             for (int k = 0; k < NV; ++k)              // v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3 (0x20 = a & ~b & c): dropped -> 0
                 cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
         }
-        if (C == 8) {
-            my_stage0[8 * (round & 15)] = (uint8_t)tags;
-            my_stage0[8 * (round & 15) + 1] = (uint8_t)(tags >> 16);
-        } else {
-            *reinterpret_cast<uint32_t *>(my_stage0 + 8 * (round & 15)) = tags;
+        if (C == 8) {                                     // cells k at bits 2k, cells k + 4 at bits 16 + 2k: one piece of 8 cells
+            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_a) = (uint16_t)((tags & 0xFFu) | ((tags >> 8) & 0xFF00u));
+        } else {                                          // cells 0 .. 7 of the lane in the low half, 8 .. 15 in the high half: two pieces
+            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_a) = (uint16_t)tags;
+            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_b) = (uint16_t)(tags >> 16);
         }
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4, std::true_type());
@@ -639,21 +651,29 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 8 alignments x 128 B per store instruction, and NO branch between them: the rows of a ragged last block past
+        // NO branch between the stores: the rows of a ragged last block past
         // alignment n - 1 hold that alignment's records once more (such lanes shadow it: same streams, same arithmetic) and
         // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
         // over; now the LDS reads go out together.
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
+        // a staged round is (centre word, outer word); four lanes take one alignment's 16 rounds, four rounds each, and part
+        // them: 16 alignments x 64 B of centre words, then of outer words, per pair of store instructions
         uint4 v[A / 8];
         if constexpr (decltype(together)::value) {
 #pragma unroll
-            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
+            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[(q / 2) * 16 + (lane >> 2)][4 * (lane & 3) + 2 * (q & 1)]);
         }
+        uint4 *centre = reinterpret_cast<uint4 *>(codes), *outer = centre + half_quads(n);
 #pragma unroll
-        for (int q = 0; q < A / 8; ++q) {
-            if constexpr (!decltype(together)::value) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 8 + (lane >> 3)][2 * (lane & 7)]);
-            const uint32_t row = min(block_first + (uint32_t)(q * 8 + (lane >> 3)), n - 1);
-            *reinterpret_cast<uint4 *>(reinterpret_cast<uint2 *>(codes) + ((size_t)g16 * n + row) * kCodeWindow + 2 * (lane & 7)) = v[q];
+        for (int q = 0; q < A / 16; ++q) {
+            if constexpr (!decltype(together)::value) {
+                v[2 * q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3)]);
+                v[2 * q + 1] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3) + 2]);
+            }
+            const uint32_t row = min(block_first + (uint32_t)(q * 16 + (lane >> 2)), n - 1);
+            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + (lane & 3);
+            centre[at] = make_uint4(v[2 * q].x, v[2 * q].z, v[2 * q + 1].x, v[2 * q + 1].z);
+            outer[at] = make_uint4(v[2 * q].y, v[2 * q].w, v[2 * q + 1].y, v[2 * q + 1].w);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -788,15 +808,17 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         const unsigned kmax2 = sg_pk_max3(sg_pk_max3(sg_pk_max3(v[0], v[1], v[2]), sg_pk_max3(v[3], v[4], v[5]), sg_pk_max3(v[6], v[7], v[8])),
                                           sg_pk_max3(sg_pk_max3(v[9], v[10], v[11]), sg_pk_max3(v[12], v[13], v[14]), v[15]), v[15]);
         // tags: the low bytes of registers k and k + 4 (k + 8 and k + 12) gathered as (cell k, k + 4, k + 16, k + 20), masked and
-        // shifted together: byte j of the two accumulators = four consecutive cells; two more gathers sort the bytes
+        // shifted together: byte j of the two accumulators = four consecutive cells; two more gathers sort the bytes into the
+        // record's centre and outer word
         unsigned acc_a = 0, acc_b = 0;
 #pragma unroll
         for (int k = 3; k >= 0; --k) {
             acc_a = (acc_a << 2) | (__builtin_amdgcn_perm(v[k + 4], v[k], 0x06020400u) & 0x03030303u);
             acc_b = (acc_b << 2) | (__builtin_amdgcn_perm(v[k + 12], v[k + 8], 0x06020400u) & 0x03030303u);
         }
-        const unsigned tags_lo = __builtin_amdgcn_perm(acc_b, acc_a, 0x05040100u);       // cells 0 .. 15, cell c at bits 2c
-        const unsigned tags_hi = __builtin_amdgcn_perm(acc_b, acc_a, 0x07060302u);       // cells 16 .. 31
+        // (acc_a bytes: cells 0-3, 4-7, 16-19, 20-23; acc_b bytes: 8-11, 12-15, 24-27, 28-31)
+        const unsigned tags_centre = __builtin_amdgcn_perm(acc_b, acc_a, 0x03020504u);   // cells 8 .. 23, cell 8 + k at bits 2k
+        const unsigned tags_outer = __builtin_amdgcn_perm(acc_b, acc_a, 0x07060100u);    // cells 0 .. 7 | 24 .. 31
         const unsigned k_lo = kmax2 & 0xFFFFu, k_hi = kmax2 >> 16;
         const int kmax = (int)(k_lo > k_hi ? k_lo : k_hi);
         // true = stored + off; a candidate derived from live cells is >= kPkFloor - 2 >= 4, one derived only from dropped cells
@@ -823,7 +845,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
                 cur[k] = __builtin_amdgcn_bitop3_b32(v[k], sg_pk_below(v[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
             alive_m &= keep_opaque(-round_best) >> 31;    // alive && round_best != 0 (:1943-1946)
         }
-        stage_codes[lane][round & 15] = make_uint2(tags_lo, tags_hi);
+        stage_codes[lane][round & 15] = make_uint2(tags_centre, tags_outer);
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4, std::true_type());
             if ((round & 31) == 31) {
@@ -954,8 +976,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
 // ascending order from (0,0) (see the kernel).
 constexpr int kMoveWords = (kMaxRound / 32 + 1 + 15) & ~15;   // uint64 words of 32 moves per alignment (1025), padded to whole
                                                          // 128-byte lines (1040): a walk's words leave sixteen at a time, one line
-constexpr int kWinQuads = kCodeWindow / 2;               // uint4 = two rounds; 8 per line
-constexpr int kLinePitch = kWinQuads + 1;                // LDS row pitch in uint4 (padded)
+constexpr int kLinePitch = kHalfQuads + 1;               // LDS row pitch in uint4 (a piece + one: conflict-free 16-byte accesses)
 
 // Inside a window the walks do not loop over their own steps (8 .. 16 of them, a different count per lane, each step one
 // chain LDS read -> decode -> (y, x) -> next address: ~400 cycles per step with one wavefront on the SIMD, 3.78 ms for 65536
@@ -1024,38 +1045,35 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     };
 
     if (loader) {
-        // The WALKS lines of a window (one per walk) lie side by side in memory: the wavefront fetches them COOPERATIVELY, 1 KB
-        // per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 8, quarter p % 8 -- and hands them to the
-        // walks through LDS.  (A ragged last block repeats the batch's last line.)
+        // The WALKS centre pieces of a window (one per walk, 64 bytes) lie side by side in memory: the wavefront fetches them
+        // COOPERATIVELY, 1 KB per instruction -- piece p = i * 64 + lane of the block belongs to walk p / 4, quarter p % 4 -- and
+        // hands them to the walks through LDS.  (A ragged last block repeats the batch's last piece.)
         const uint4 *all_codes = reinterpret_cast<const uint4 *>(codes);
-        static_assert(kWinQuads == 8, "eight pieces per window");
-        auto piece_offset = [&](int i) -> uint32_t {      // uint4 offset of this lane's piece i inside a window's lines
-            const uint32_t w_a = a_first + (uint32_t)((i * 64 + lane) >> 3);
-            return (w_a < n ? w_a : n - 1) * kWinQuads + (uint32_t)(lane & 7);
+        static_assert(kHalfQuads == 4, "four quarters per piece");
+        auto piece_offset = [&](int i) -> uint32_t {      // uint4 offset of this lane's quarter i inside a window's pieces
+            const uint32_t w_a = a_first + (uint32_t)((i * 64 + lane) >> 2);
+            return (w_a < n ? w_a : n - 1) * kHalfQuads + (uint32_t)(lane & 3);
         };
-        const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3), o4 = piece_offset(4),
-                       o5 = piece_offset(5), o6 = piece_offset(6), o7 = piece_offset(7);
-        uint4 *my_slot = &line_codes[0][(lane >> 3) * kLinePitch + (lane & 7)];      // piece i goes 8 walks (rows) further down
+        const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3);
+        uint4 *my_slot = &line_codes[0][(lane >> 2) * kLinePitch + (lane & 3)];      // quarter i goes 16 walks (rows) further down
         constexpr int kSlot = WALKS * kLinePitch;                                    // uint4 per LDS slot
-        // (the eight pieces of a window are sixteen plain variables and two macros: arrays or structs handed to lambdas by
+        // (the four quarters of a window are eight plain variables and two macros: arrays or structs handed to lambdas by
         // reference stayed in scratch memory in round 3)
 #define SG_LOAD_WINDOW(w, P)                                                                                          \
         do {                                                                                                          \
             const int w_ = SG_WALK_EXP == 1 ? 0 : (w) > 0 ? ((w) < kCodeWindows ? (w) : kCodeWindows - 1) : 0;       \
-            const uint4 *base_ = all_codes + (size_t)w_ * n * kWinQuads;                                              \
+            const uint4 *base_ = all_codes + (size_t)w_ * n * kHalfQuads;                                             \
             P##0 = base_[o0]; P##1 = base_[o1]; P##2 = base_[o2]; P##3 = base_[o3];                                   \
-            P##4 = base_[o4]; P##5 = base_[o5]; P##6 = base_[o6]; P##7 = base_[o7];                                   \
         } while (0)
 #define SG_TO_LDS(P, slot)                                                                                            \
         do {                                                                                                          \
             uint4 *dst_ = my_slot + (slot) * kSlot;                                                                   \
-            dst_[0 * 8 * kLinePitch] = P##0; dst_[1 * 8 * kLinePitch] = P##1; dst_[2 * 8 * kLinePitch] = P##2;        \
-            dst_[3 * 8 * kLinePitch] = P##3; dst_[4 * 8 * kLinePitch] = P##4; dst_[5 * 8 * kLinePitch] = P##5;        \
-            dst_[6 * 8 * kLinePitch] = P##6; dst_[7 * 8 * kLinePitch] = P##7;                                         \
+            dst_[0 * 16 * kLinePitch] = P##0; dst_[1 * 16 * kLinePitch] = P##1; dst_[2 * 16 * kLinePitch] = P##2;     \
+            dst_[3 * 16 * kLinePitch] = P##3;                                                                         \
         } while (0)
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4, wa4 = z4, wa5 = z4, wa6 = z4, wa7 = z4;
-        uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4, wb4 = z4, wb5 = z4, wb6 = z4, wb7 = z4;
+        uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4;
+        uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4;
         const uint32_t *my_dirs = dirs + a;               // word b of walk `lane` at my_dirs[b * n]: 256 contiguous bytes per wavefront
         unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
         count_lds[lane] = 0u;
@@ -1120,30 +1138,62 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         if (blk == start_blk) rights_before = (sum.y - sum.w) - __popc(d_blk & ((2u << (sum.y & 31)) - 1u));
     };
     enter_block();
+    const uint4 *my_outer = reinterpret_cast<const uint4 *>(codes) + half_quads(n) + (size_t)a * kHalfQuads;     // + window * n * kHalfQuads
     auto walk_window = [&](int w, const bool upper, const uint4 *my_line) {   // upper: window 2 blk + 1 of its block (a constant at every call)
-        uint4 rec[kWinQuads];                             // rounds 16 w + 2 j (.x, .y) and 16 w + 2 j + 1 (.z, .w)
+        uint4 rec[kHalfQuads];                            // centre words of rounds 16 w + 4 j .. + 3 (.x .. .w)
 #pragma unroll
-        for (int j = 0; j < kWinQuads; ++j) rec[j] = my_line[j];
+        for (int j = 0; j < kHalfQuads; ++j) rec[j] = my_line[j];
         // the window's 16 move bits and the right moves before it
         const unsigned d_win = upper ? d_blk >> 16 : d_blk & 0xFFFFu;
         const int rb_win = rights_before + (upper ? (int)__popc(d_blk & 0xFFFFu) : 0);
         unsigned wm = 0;                                  // this window's moves, cnt2 / 2 of them
         int cnt2 = 0;
+        const int nr_in = nr, ny2_in = ny2;
+        // FIRST with the centre words alone: a step whose band cell is not one of 8 .. 23 reads nonsense and raises `astray`
+        unsigned long long astray = 0;                    // (a scalar pair: one v_cmp + one s_or per round)
 #pragma unroll
         for (int i = kCodeWindow - 1; i >= 0; --i) {
             if (i > 0 || w > 0) {                         // (round 0 is the cell (0, 0): nothing to decode)
                 const int rho = kCodeWindow * w + i;
-                const unsigned long long cw = i & 1 ? ((unsigned long long)rec[i / 2].w << 32) | rec[i / 2].z
-                                                    : ((unsigned long long)rec[i / 2].y << 32) | rec[i / 2].x;
+                const unsigned cw = i % 4 == 0 ? rec[i / 4].x : i % 4 == 1 ? rec[i / 4].y : i % 4 == 2 ? rec[i / 4].z : rec[i / 4].w;
                 // band row of round rho = rho - (right moves up to and including rho); 2 * band cell of the walk = 2 (31 + top) - 2 y
                 const int rights = rb_win + (int)__popc(d_win & ((2u << i) - 1u));
-                const int shift = 2 * (31 + rho - rights) + ny2;
+                const int shift = 2 * (31 + rho - rights) + ny2 - 16;         // inside the centre word: 0 .. 30
                 const int active = keep_opaque(nr + (rho - 1)) >> 31;         // r == rho (r <= rho always): all ones
-                const unsigned tag = (unsigned)(cw >> (shift & 63)) & 3u & (unsigned)active;    // 3 diagonal, 2 up, 1 left (never 0 on a live path)
+                astray |= __builtin_amdgcn_uicmp((unsigned)shift & (unsigned)active, 30u, 34 /* ICMP_UGT */);
+                const unsigned tag = (cw >> (shift & 31)) & 3u & (unsigned)active;    // 3 diagonal, 2 up, 1 left (never 0 on a live path)
                 ny2 += (int)(tag & 2u);                   // diagonal, up: one row back
                 nr += (int)__popc(tag);                   // diagonal: two rounds back, up / left: one
                 wm |= tag << cnt2;
                 cnt2 -= 2 * active;
+            }
+        }
+        if (astray != 0) {                                // (wavefront-uniform) some walk left the centre: the window again, whole records
+            nr = nr_in;
+            ny2 = ny2_in;
+            wm = 0;
+            cnt2 = 0;
+            const int w_ = SG_WALK_EXP == 1 ? 0 : w;
+            uint4 out[kHalfQuads];                        // this walk's outer piece, straight from memory (the one place the decoder loads)
+#pragma unroll
+            for (int j = 0; j < kHalfQuads; ++j) out[j] = my_outer[(size_t)w_ * n * kHalfQuads + j];
+#pragma unroll
+            for (int i = kCodeWindow - 1; i >= 0; --i) {
+                if (i > 0 || w > 0) {
+                    const int rho = kCodeWindow * w + i;
+                    const unsigned c = i % 4 == 0 ? rec[i / 4].x : i % 4 == 1 ? rec[i / 4].y : i % 4 == 2 ? rec[i / 4].z : rec[i / 4].w;
+                    const unsigned o = i % 4 == 0 ? out[i / 4].x : i % 4 == 1 ? out[i / 4].y : i % 4 == 2 ? out[i / 4].z : out[i / 4].w;
+                    // cells 0 .. 31 at bits 2k: outer low half, centre, outer high half
+                    const unsigned long long cw = ((unsigned long long)((c >> 16) | (o & 0xFFFF0000u)) << 32) | ((o & 0xFFFFu) | (c << 16));
+                    const int rights = rb_win + (int)__popc(d_win & ((2u << i) - 1u));
+                    const int shift = 2 * (31 + rho - rights) + ny2;
+                    const int active = keep_opaque(nr + (rho - 1)) >> 31;
+                    const unsigned tag = (unsigned)(cw >> (shift & 63)) & 3u & (unsigned)active;
+                    ny2 += (int)(tag & 2u);
+                    nr += (int)__popc(tag);
+                    wm |= tag << cnt2;
+                    cnt2 -= 2 * active;
+                }
             }
         }
         // the window's moves behind the ones collected so far; a full word of 32 leaves
