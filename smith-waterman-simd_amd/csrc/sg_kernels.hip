@@ -1014,7 +1014,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
 {
     constexpr int WALKS = 64;
     constexpr int kRing = 32;                             // move words per walk in LDS: the loader flushes 16 as soon as it sees 16
-    __shared__ uint4 line_codes[2][WALKS * kLinePitch];   // two slots of [walk][two rounds], padded
+    __shared__ uint4 line_codes[2][2][WALKS * kLinePitch];   // two slots of a BLOCK (32 rounds): [upper / lower window][walk][piece], padded
     __shared__ uint32_t dirs_lds[2][WALKS];               // move bits of block b for every walk, slot b & 1 (loader -> decoder)
     __shared__ unsigned long long ring_lds[WALKS][kRing + 1];   // finished move words of every walk, word i in slot i % kRing (row padded)
     __shared__ uint32_t count_lds[WALKS];                 // words finished so far per walk (decoder -> loader, once per trip)
@@ -1035,8 +1035,8 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     // window, so it passes without a step (its records are fetched but never looked at; past the last window of the buffer the
     // last one is fetched again).  Window w_top - i is processed in trip i and lives in LDS slot i & 1.
     const int w_top = wmax | 1;
-    // One barrier per window: before it the loader has put window (trip + 1) into the other slot and the decoder has finished
-    // reading this trip's slot.  Only LDS traffic has to be visible across it (the fence names the local address space: a
+    // One barrier per block of two windows: before it the loader has put the next block into the other slot and the decoder has
+    // finished reading this trip's slot.  Only LDS traffic has to be visible across it (the fence names the local address space: a
     // plain workgroup fence would also wait for the loader's global loads, i.e. drain its prefetch).
     auto window_barrier = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1055,8 +1055,8 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
             return (w_a < n ? w_a : n - 1) * kHalfQuads + (uint32_t)(lane & 3);
         };
         const uint32_t o0 = piece_offset(0), o1 = piece_offset(1), o2 = piece_offset(2), o3 = piece_offset(3);
-        uint4 *my_slot = &line_codes[0][(lane >> 2) * kLinePitch + (lane & 3)];      // quarter i goes 16 walks (rows) further down
-        constexpr int kSlot = WALKS * kLinePitch;                                    // uint4 per LDS slot
+        uint4 *my_slot = &line_codes[0][0][(lane >> 2) * kLinePitch + (lane & 3)];   // quarter i goes 16 walks (rows) further down
+        constexpr int kSlot = WALKS * kLinePitch;                                    // uint4 per window in LDS (slot s, half h: (2 s + h) * kSlot)
         // (the four quarters of a window are eight plain variables and two macros: arrays or structs handed to lambdas by
         // reference stayed in scratch memory in round 3)
 #define SG_LOAD_WINDOW(w, P)                                                                                          \
@@ -1072,8 +1072,8 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
             dst_[3 * 16 * kLinePitch] = P##3;                                                                         \
         } while (0)
         const uint4 z4 = make_uint4(0, 0, 0, 0);
-        uint4 wa0 = z4, wa1 = z4, wa2 = z4, wa3 = z4;
-        uint4 wb0 = z4, wb1 = z4, wb2 = z4, wb3 = z4;
+        uint4 au0 = z4, au1 = z4, au2 = z4, au3 = z4, al0 = z4, al1 = z4, al2 = z4, al3 = z4;      // a block's upper and lower window
+        uint4 bu0 = z4, bu1 = z4, bu2 = z4, bu3 = z4, bl0 = z4, bl1 = z4, bl2 = z4, bl3 = z4;      // the block below it
         const uint32_t *my_dirs = dirs + a;               // word b of walk `lane` at my_dirs[b * n]: 256 contiguous bytes per wavefront
         unsigned long long *my_moves = moves + (size_t)a * kMoveWords;
         count_lds[lane] = 0u;
@@ -1094,20 +1094,31 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
                 flushed += 16u;
             }
         };
-        SG_LOAD_WINDOW(w_top, wa);
-        SG_LOAD_WINDOW(w_top - 1, wb);
-        SG_TO_LDS(wa, 0);
-        window_barrier();                                 // trip 0 may start: window w_top is in slot 0
-        // trip i (window w = w_top - i in slot i & 1): request window w - 2, put window w - 1 into the other slot
+        // A TRIP IS A BLOCK of two windows (one barrier per 32 rounds; with one per window the barriers were a third of the
+        // kernel).  Block blk = windows 2 blk + 1 (upper) and 2 blk (lower) lives in LDS slot (top block - blk) & 1; while the
+        // decoder walks it, the loader requests block blk - 2 and puts block blk - 1 (requested a trip ago) into the other slot.
         int blk = w_top / 2;
-        for (int w = w_top;;) {                           // w is odd here: the upper window of block blk
-            const int nb = blk > 0 ? blk - 1 : 0;         // (block 0 again below block 0: never used)
-            const unsigned d_next = my_dirs[(size_t)nb * n];
-            SG_LOAD_WINDOW(w - 2, wa); drain(); SG_TO_LDS(wb, 1); window_barrier(); --w;
-            SG_LOAD_WINDOW(w - 2, wb); drain(); if (w == 0) break;
-            dirs_lds[nb & 1][lane] = d_next;              // before the barrier at which the decoder steps down into block nb
-            SG_TO_LDS(wa, 0); window_barrier(); --w;
-            --blk;
+        SG_LOAD_WINDOW(2 * blk + 1, au); SG_LOAD_WINDOW(2 * blk, al);
+        SG_LOAD_WINDOW(2 * blk - 1, bu); SG_LOAD_WINDOW(2 * blk - 2, bl);
+        SG_TO_LDS(au, 0); SG_TO_LDS(al, 1);
+        window_barrier();                                 // trip 0 may start: the top block is in slot 0
+        for (;;) {                                        // (two trips per turn: the register sets and the slots swap roles)
+            {
+                const int nb = blk > 0 ? blk - 1 : 0;     // (block 0 again below block 0: never used)
+                const unsigned d_next = my_dirs[(size_t)nb * n];
+                SG_LOAD_WINDOW(2 * blk - 3, au); SG_LOAD_WINDOW(2 * blk - 4, al); drain();
+                if (blk == 0) break;
+                dirs_lds[nb & 1][lane] = d_next;          // before the barrier at which the decoder steps down into block nb
+                SG_TO_LDS(bu, 2); SG_TO_LDS(bl, 3); window_barrier(); --blk;
+            }
+            {
+                const int nb = blk > 0 ? blk - 1 : 0;
+                const unsigned d_next = my_dirs[(size_t)nb * n];
+                SG_LOAD_WINDOW(2 * blk - 3, bu); SG_LOAD_WINDOW(2 * blk - 4, bl); drain();
+                if (blk == 0) break;
+                dirs_lds[nb & 1][lane] = d_next;
+                SG_TO_LDS(au, 0); SG_TO_LDS(al, 1); window_barrier(); --blk;
+            }
         }
 #undef SG_LOAD_WINDOW
 #undef SG_TO_LDS
@@ -1212,13 +1223,14 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         rights_before -= (int)__popc(d_blk);
         enter_block();
     };
-    const uint4 *line0 = &line_codes[0][lane * kLinePitch], *line1 = &line_codes[1][lane * kLinePitch];
-    window_barrier();                                     // window w_top is in slot 0
-    for (int w = w_top;;) {                               // w is odd here: the upper window of block blk, in slot 0
-        walk_window(w, true, line0); window_barrier(); --w;
-        walk_window(w, false, line1); if (w == 0) break; window_barrier();
+    const uint4 *up0 = &line_codes[0][0][lane * kLinePitch], *lo0 = &line_codes[0][1][lane * kLinePitch];
+    const uint4 *up1 = &line_codes[1][0][lane * kLinePitch], *lo1 = &line_codes[1][1][lane * kLinePitch];
+    window_barrier();                                     // the top block is in slot 0
+    for (;;) {                                            // blk: the block in slot 0
+        walk_window(2 * blk + 1, true, up0); walk_window(2 * blk, false, lo0); if (blk == 0) break; window_barrier();
         step_down();
-        --w;
+        walk_window(2 * blk + 1, true, up1); walk_window(2 * blk, false, lo1); if (blk == 0) break; window_barrier();
+        step_down();
     }
     if (steps & 31u) {                                    // the last, partial word goes the same way
         ring_lds[lane][(steps >> 5) % kRing] = acc;
