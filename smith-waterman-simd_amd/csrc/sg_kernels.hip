@@ -44,6 +44,7 @@ constexpr int kMaxRound = 2 * (kLen + 1) - 1;   // MAX_ROUND, source.cpp:1875
 constexpr int kCodeWindow = 16;                           // rounds per piece
 constexpr int kCodeWindows = (kMaxRound + kCodeWindow - 1) / kCodeWindow;
 constexpr int kHalfQuads = kCodeWindow / 4;               // uint4 per piece (64 bytes)
+constexpr int kStagePitch = kCodeWindow + 4;              // a sweep's LDS staging row per alignment and half, in words: 80 bytes
 __device__ __forceinline__ size_t half_quads(uint32_t n) { return (size_t)kCodeWindows * n * kHalfQuads; }   // uint4 per half array
 // move bits: bit (r & 31) of word r >> 5 = 1 when the band stepped right in round r (source.cpp:1895); stored
 // word-major, dirs[word * n + alignment], so that the writers and the readers of neighbouring alignments share lines
@@ -287,7 +288,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     using win_t = typename std::conditional<C == 8, uint32_t, unsigned long long>::type;   // C 4-bit fields
     // sixteen rounds of code records per alignment are staged here and leave as ONE 128-byte line per alignment: a
     // 64-byte piece of a 128-byte L2 line costs a read-for-ownership of the whole line on top of the write
-    __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]
+    __shared__ __attribute__((aligned(16))) uint32_t stage_codes[2][A][kStagePitch];   // [centre / outer word][alignment of the block][round & 15] (+ 4: see the flush)
     const int lane = threadIdx.x;
     const int g = lane & (G - 1);                         // slice of the band: cells g*C .. g*C + C-1
     const int al = lane / G;                              // alignment of the block
@@ -301,12 +302,13 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     const unsigned long long *stream_a = streams + (size_t)blockIdx.x * kStreamWords * kStreamStride + 2 * al;
     const unsigned long long *stream_b = stream_a + 1;
     // this slice's bytes of the round's 8-byte code record: cell k of the band at bits 2k, 2k+1
-    // (a staged record = centre word, cells 8 .. 23, then outer word, cells 0 .. 7 | 24 .. 31: byte offsets 0 and 4).  The
-    // lane's cells in 16-bit pieces of 8: piece j of the band goes to offset 4, 0, 2, 6 for j = 0 .. 3
+    // The lane's cells in 16-bit pieces of 8: piece j of the band is the low half of the outer word, the low and the high
+    // half of the centre word (cells 8 .. 23), the high half of the outer word for j = 0 .. 3
     const int piece0 = g * C / 8;                         // first piece of this lane (C / 8 pieces: 1 or 2)
-    uint8_t *my_stage0 = reinterpret_cast<uint8_t *>(&stage_codes[al][0]);
-    const int off_a = piece0 == 0 ? 4 : piece0 == 1 ? 0 : piece0 == 2 ? 2 : 6;
-    const int off_b = piece0 + 1 == 1 ? 0 : 6;            // (C = 16: the lane's second piece is piece 1 or 3)
+    auto piece_home = [&](int j) -> uint8_t * {
+        return reinterpret_cast<uint8_t *>(&stage_codes[j == 1 || j == 2 ? 0 : 1][al][0]) + (j >= 2 ? 2 : 0);
+    };
+    uint8_t *const stage_a = piece_home(piece0), *const stage_b = piece_home(piece0 + 1);     // (stage_b: C = 16 only)
     uint32_t *my_dirs = dirs + a;                         // word w at my_dirs[w * n]
     auto flush_codes = [&](int g16, auto together) {      // rounds 16 * g16 .. 16 * g16 + 15 of every alignment of the block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -317,24 +319,28 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
         // over; now the LDS reads go out together.
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
-        // a staged round is (centre word, outer word); four lanes take one alignment's 16 rounds, four rounds each, and part
-        // them: 16 alignments x 64 B of centre words, then of outer words, per pair of store instructions
-        uint4 v[A / 8];
+        // the centre words and the outer words are staged apart, 16 rounds per alignment in a row: four lanes take one
+        // alignment's row, four rounds each -- 16 alignments x 64 B of centre words, then of outer words, per pair of store
+        // instructions; neighbouring lanes take neighbouring ALIGNMENTS (rows 80 bytes = 20 banks apart).  (Staged as
+        // (centre, outer) pairs the words had to be parted in registers: 32 moves per flush.)
+        const int fa16 = lane & 15, part = lane >> 4;
+        uint4 vc[A / 16], vo[A / 16];
+        auto fetch = [&](int q) {
+            vc[q] = *reinterpret_cast<const uint4 *>(&stage_codes[0][q * 16 + fa16][4 * part]);
+            vo[q] = *reinterpret_cast<const uint4 *>(&stage_codes[1][q * 16 + fa16][4 * part]);
+        };
         if constexpr (decltype(together)::value) {
 #pragma unroll
-            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[(q / 2) * 16 + (lane >> 2)][4 * (lane & 3) + 2 * (q & 1)]);
+            for (int q = 0; q < A / 16; ++q) fetch(q);
         }
         uint4 *centre = reinterpret_cast<uint4 *>(codes), *outer = centre + half_quads(n);
 #pragma unroll
         for (int q = 0; q < A / 16; ++q) {
-            if constexpr (!decltype(together)::value) {
-                v[2 * q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3)]);
-                v[2 * q + 1] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3) + 2]);
-            }
-            const uint32_t row = min(block_first + (uint32_t)(q * 16 + (lane >> 2)), n - 1);
-            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + (lane & 3);
-            centre[at] = make_uint4(v[2 * q].x, v[2 * q].z, v[2 * q + 1].x, v[2 * q + 1].z);
-            outer[at] = make_uint4(v[2 * q].y, v[2 * q].w, v[2 * q + 1].y, v[2 * q + 1].w);
+            if constexpr (!decltype(together)::value) fetch(q);
+            const uint32_t row = min(block_first + (uint32_t)(q * 16 + fa16), n - 1);
+            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + part;
+            centre[at] = vc[q];
+            outer[at] = vo[q];
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -390,7 +396,7 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     int best = kXDrop, best_round = 0, best_kmax = 31 << 2, best_px = 31, last_round = 0;
     int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
-    if (is_first) stage_codes[al][0] = make_uint2(0, 0);
+    if (is_first) stage_codes[0][al][0] = stage_codes[1][al][0] = 0u;
     // This lane's character stream: the first slice feeds on seq1 (consumed when the band steps down), the last slice on
     // seq2 (consumed when it steps right); slices in between run the seq1 stream along without using it.
     SgStream feed;
@@ -528,10 +534,10 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
                 cur[k] = (int)__builtin_amdgcn_bitop3_b32((unsigned)cur[k], sg_pk_below((unsigned)cur[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
         }
         if (C == 8) {                                     // cells k at bits 2k, cells k + 4 at bits 16 + 2k: one piece of 8 cells
-            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_a) = (uint16_t)((tags & 0xFFu) | ((tags >> 8) & 0xFF00u));
+            *reinterpret_cast<uint16_t *>(stage_a + 4 * (round & 15)) = (uint16_t)((tags & 0xFFu) | ((tags >> 8) & 0xFF00u));
         } else {                                          // cells 0 .. 7 of the lane in the low half, 8 .. 15 in the high half: two pieces
-            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_a) = (uint16_t)tags;
-            *reinterpret_cast<uint16_t *>(my_stage0 + 8 * (round & 15) + off_b) = (uint16_t)(tags >> 16);
+            *reinterpret_cast<uint16_t *>(stage_a + 4 * (round & 15)) = (uint16_t)tags;
+            *reinterpret_cast<uint16_t *>(stage_b + 4 * (round & 15)) = (uint16_t)(tags >> 16);
         }
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4, std::true_type());
@@ -638,7 +644,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
                        uint32_t *__restrict__ window_stats)
 {
     constexpr int NV = 16, A = 64;
-    __shared__ uint2 stage_codes[A][16];                  // [alignment of the block][round & 15]: one 128-byte line each per flush
+    __shared__ __attribute__((aligned(16))) uint32_t stage_codes[2][A][kStagePitch];   // [centre / outer word][alignment of the block][round & 15] (+ 4: see the flush)
     const int lane = threadIdx.x;
     const uint32_t block_first = blockIdx.x * A;
     const uint32_t a0 = block_first + lane;
@@ -656,24 +662,28 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         // are stored on top of its row -- the same bytes.  With a test per store the block was read, wait, store eight times
         // over; now the LDS reads go out together.
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
-        // a staged round is (centre word, outer word); four lanes take one alignment's 16 rounds, four rounds each, and part
-        // them: 16 alignments x 64 B of centre words, then of outer words, per pair of store instructions
-        uint4 v[A / 8];
+        // the centre words and the outer words are staged apart, 16 rounds per alignment in a row: four lanes take one
+        // alignment's row, four rounds each -- 16 alignments x 64 B of centre words, then of outer words, per pair of store
+        // instructions; neighbouring lanes take neighbouring ALIGNMENTS (rows 80 bytes = 20 banks apart).  (Staged as
+        // (centre, outer) pairs the words had to be parted in registers: 32 moves per flush.)
+        const int fa16 = lane & 15, part = lane >> 4;
+        uint4 vc[A / 16], vo[A / 16];
+        auto fetch = [&](int q) {
+            vc[q] = *reinterpret_cast<const uint4 *>(&stage_codes[0][q * 16 + fa16][4 * part]);
+            vo[q] = *reinterpret_cast<const uint4 *>(&stage_codes[1][q * 16 + fa16][4 * part]);
+        };
         if constexpr (decltype(together)::value) {
 #pragma unroll
-            for (int q = 0; q < A / 8; ++q) v[q] = *reinterpret_cast<const uint4 *>(&stage_codes[(q / 2) * 16 + (lane >> 2)][4 * (lane & 3) + 2 * (q & 1)]);
+            for (int q = 0; q < A / 16; ++q) fetch(q);
         }
         uint4 *centre = reinterpret_cast<uint4 *>(codes), *outer = centre + half_quads(n);
 #pragma unroll
         for (int q = 0; q < A / 16; ++q) {
-            if constexpr (!decltype(together)::value) {
-                v[2 * q] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3)]);
-                v[2 * q + 1] = *reinterpret_cast<const uint4 *>(&stage_codes[q * 16 + (lane >> 2)][4 * (lane & 3) + 2]);
-            }
-            const uint32_t row = min(block_first + (uint32_t)(q * 16 + (lane >> 2)), n - 1);
-            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + (lane & 3);
-            centre[at] = make_uint4(v[2 * q].x, v[2 * q].z, v[2 * q + 1].x, v[2 * q + 1].z);
-            outer[at] = make_uint4(v[2 * q].y, v[2 * q].w, v[2 * q + 1].y, v[2 * q + 1].w);
+            if constexpr (!decltype(together)::value) fetch(q);
+            const uint32_t row = min(block_first + (uint32_t)(q * 16 + fa16), n - 1);
+            const size_t at = ((size_t)g16 * n + row) * kHalfQuads + part;
+            centre[at] = vc[q];
+            outer[at] = vo[q];
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -706,7 +716,7 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
     int best = kXDrop, best_round = 0, best_kmax = 31 << 2, best_px = 31, last_round = 0;
     int alive_m = -1;                                     // all ones while the alignment is alive
     unsigned dir_word = 0;                                // move bits of the current 32 rounds (round r ends at bit r & 31)
-    stage_codes[lane][0] = make_uint2(0, 0);
+    stage_codes[0][lane][0] = stage_codes[1][lane][0] = 0u;
 
     // the calm loop's windows (below): 2 bits per cell, cell c at bits 2c -- bases only
     unsigned long long a2 = 0, b2 = 0;
@@ -845,7 +855,8 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
                 cur[k] = __builtin_amdgcn_bitop3_b32(v[k], sg_pk_below(v[k], thr2), ~((unsigned)(kScale - 1) * 0x10001u), 0x20);
             alive_m &= keep_opaque(-round_best) >> 31;    // alive && round_best != 0 (:1943-1946)
         }
-        stage_codes[lane][round & 15] = make_uint2(tags_centre, tags_outer);
+        stage_codes[0][lane][round & 15] = tags_centre;   // (one ds_write2st64_b32)
+        stage_codes[1][lane][round & 15] = tags_outer;
         if (K == 6 && (base & 8)) {                       // round = 15 (mod 16): same place for every lane of the wavefront
             flush_codes(round >> 4, std::true_type());
             if ((round & 31) == 31) {
