@@ -460,12 +460,14 @@ def bench_semiglobal(args, swmi, np, torch, local_rank, steps=None, warmup=None)
     # which no cell can reach the threshold); the library counts how many windows of the last call were calm.  The record
     # flush and the stream top-up each sit behind ONE of a loop's eight rounds under a test of the window's number: they run on
     # every second trip.
-    windows, calm_windows = swmi.semiglobal_window_stats(stream.cuda_stream)
+    windows, calm_windows, walk_windows, walk_again = swmi.semiglobal_window_stats(stream.cuda_stream, walk=True)
     calm_share = calm_windows / windows if windows else 0.0
     roof = issue_bound("^" + name + "$", rounds * (1.0 - calm_share), (P + per_wave - 1) // per_wave, sweep_ms, marker=marker,
                        conditional_share=0.5, pick="most",
                        second={"marker": ("v_pk_maximum3_f16", marker[1] * 3 // 2), "exclude": marker[0], "trips": rounds * calm_share})
     roof["calm_window_share"] = round(calm_share, 4)
+    # the traceback fetches the records of band cells 8 .. 23 only; a window in which a walk leaves them is decoded a second time
+    roof["walk_windows_decoded_twice_share"] = round(walk_again / walk_windows, 4) if walk_windows else None
     traffic, traffic_src = sg_traffic(P, sweep_kernel, roof.get("kernel_code_sha256"))
     roof.update({
         "kernel_ms": round(sweep_ms, 3), "traceback_kernels": tb_kernel, "traceback_kernel_ms": round(tb_ms, 3),
@@ -609,8 +611,9 @@ def row_summary(line):
         out["two_calls_in_flight"] = line["two_calls_in_flight"]
     if line.get("exact_path_forced"):
         out["exact_path_forced"] = line["exact_path_forced"]
-    if r.get("calm_window_share") is not None:
-        out["calm_window_share"] = r["calm_window_share"]
+    for k in ("calm_window_share", "walk_windows_decoded_twice_share"):
+        if r.get(k) is not None:
+            out[k] = r[k]
     return out
 
 

@@ -282,9 +282,11 @@ SWMI_API int swmi_semiglobal_set_mapping(int sweep);
  * value at swmi_init*. */
 SWMI_API int swmi_semiglobal_set_exact(int exact_only);
 /* What the last swmi_semiglobal_xdrop[_moves]_device call on `stream` of the current GPU ran: counts[0] = windows of 8 rounds
- * summed over its sweep wavefronts, counts[1] = how many of them were calm (no X-drop test).  Waits for the stream.
- * SWMI_ERR_INVALID_ARGUMENT when no call has run on that stream. */
-SWMI_API int swmi_semiglobal_window_stats(void *stream, uint64_t counts[2]);
+ * summed over its sweep wavefronts, counts[1] = how many of them were calm (no X-drop test); counts[2] = windows of 16 rounds
+ * summed over its traceback wavefronts, counts[3] = how many of them were decoded a second time because a walk left band cells
+ * 8 .. 23 (the traceback fetches that half of the predecessor records only, the other half on demand: DESIGN.md section 10).
+ * Waits for the stream.  SWMI_ERR_INVALID_ARGUMENT when no call has run on that stream. */
+SWMI_API int swmi_semiglobal_window_stats(void *stream, uint64_t counts[4]);
 /* Free the per-stream workspaces of the current GPU (synchronises the device first). */
 SWMI_API int swmi_semiglobal_release_workspaces(void);
 /* Names of the sweep and traceback kernels a call with n alignments runs on the current GPU (the mapping depends on the

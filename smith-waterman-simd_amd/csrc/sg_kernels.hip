@@ -1021,7 +1021,7 @@ constexpr int kLinePitch = kHalfQuads + 1;               // LDS row pitch in uin
 __global__ void __launch_bounds__(128)
 sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32_t *__restrict__ dirs,
                     const int4 *__restrict__ summary, unsigned long long *__restrict__ moves,
-                    int32_t *__restrict__ scores, uint32_t *__restrict__ lengths)
+                    int32_t *__restrict__ scores, uint32_t *__restrict__ lengths, uint32_t *__restrict__ window_stats)
 {
     constexpr int WALKS = 64;
     constexpr int kRing = 32;                             // move words per walk in LDS: the loader flushes 16 as soon as it sees 16
@@ -1161,6 +1161,7 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
     };
     enter_block();
     const uint4 *my_outer = reinterpret_cast<const uint4 *>(codes) + half_quads(n) + (size_t)a * kHalfQuads;     // + window * n * kHalfQuads
+    uint32_t windows_walked = 0, windows_again = 0;       // (scalars; summed over the launch into window_stats[2], [3])
     auto walk_window = [&](int w, const bool upper, const uint4 *my_line) {   // upper: window 2 blk + 1 of its block (a constant at every call)
         uint4 rec[kHalfQuads];                            // centre words of rounds 16 w + 4 j .. + 3 (.x .. .w)
 #pragma unroll
@@ -1190,7 +1191,9 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
                 cnt2 -= 2 * active;
             }
         }
+        ++windows_walked;
         if (astray != 0) {                                // (wavefront-uniform) some walk left the centre: the window again, whole records
+            ++windows_again;
             nr = nr_in;
             ny2 = ny2_in;
             wm = 0;
@@ -1248,6 +1251,10 @@ sg_walk_lane_kernel(uint32_t n, const uint32_t *__restrict__ codes, const uint32
         count_lds[lane] = (steps >> 5) + 1u;
     }
     window_barrier();                                     // the loader writes out what is left in the ring
+    if (lane == 0) {
+        atomicAdd(&window_stats[2], windows_walked);
+        atomicAdd(&window_stats[3], windows_again);
+    }
     if (real) {
         scores[a] = sum.x;
         lengths[a] = steps + 1;                           // positions = moves + 1
@@ -1437,8 +1444,8 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
                              hipEvent_t between, int compute_units, SgTuning tuning, unsigned long long *d_moves_out)
 {
     if (n == 0) return hipSuccess;
-    // the first line of the workspace: windows of the last launch's sweep wavefronts, [0] all, [1] calm (64-bit sums would need
-    // nothing more: 4096 wavefronts x 4096 windows stay below 2^32)
+    // the first line of the workspace: windows of the last launch's sweep wavefronts, [0] all, [1] calm; of its walk wavefronts,
+    // [2] all, [3] decoded a second time with the records' outer halves (4096 wavefronts x 4096 windows stay below 2^32)
     uint32_t *window_stats = static_cast<uint32_t *>(d_workspace);
     {
         const hipError_t ez = hipMemsetAsync(window_stats, 0, kStatsBytes, stream);
@@ -1484,7 +1491,7 @@ hipError_t launch_semiglobal(const uint8_t *d_seq1s, const uint8_t *d_seq2s, siz
     if (e == hipSuccess && between) e = hipEventRecord(between, stream);      // phase timing (swmi_semiglobal_time_device)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sg_walk_lane_kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, stream, (uint32_t)n, codes, top, summary,
-                       moves, d_scores, d_lengths);
+                       moves, d_scores, d_lengths, window_stats);
     if (d_tracebacks || !d_moves_out)           // (moves only: the caller expands them itself, swmi_semiglobal_expand_moves)
         hipLaunchKernelGGL(sg_expand_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (uint32_t)n, moves, d_lengths,
                            d_tracebacks, (uint32_t)cap);

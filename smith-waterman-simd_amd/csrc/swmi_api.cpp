@@ -1166,10 +1166,10 @@ int swmi_semiglobal_set_exact(int exact_only)
     return SWMI_OK;
 }
 
-int swmi_semiglobal_window_stats(void *stream, uint64_t counts[2])
+int swmi_semiglobal_window_stats(void *stream, uint64_t counts[4])
 {
     if (!counts) return fail(SWMI_ERR_INVALID_ARGUMENT, "counts is NULL");
-    counts[0] = counts[1] = 0;
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
     Context *ctx = current();
     if (!ctx) return last_status();
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1177,11 +1177,10 @@ int swmi_semiglobal_window_stats(void *stream, uint64_t counts[2])
     const auto it = ctx->sg_workspaces.find(st);
     if (it == ctx->sg_workspaces.end() || !it->second.ptr)
         return fail(SWMI_ERR_INVALID_ARGUMENT, "no semi-global call has run on this stream");
-    uint32_t raw[2] = {0, 0};
+    uint32_t raw[4] = {0, 0, 0, 0};
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(raw, it->second.ptr, sizeof raw, hipMemcpyDeviceToHost));     // the first words of the workspace (sg_kernels.hip)
-    counts[0] = raw[0];
-    counts[1] = raw[1];
+    for (int k = 0; k < 4; ++k) counts[k] = raw[k];
     return SWMI_OK;
 }
 

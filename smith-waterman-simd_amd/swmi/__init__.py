@@ -472,11 +472,12 @@ def semiglobal_set_exact(exact_only=False):
     _check(load().swmi_semiglobal_set_exact(1 if exact_only else 0))
 
 
-def semiglobal_window_stats(stream=0):
-    """(windows of 8 rounds the sweep wavefronts of the last device call on `stream` ran, how many of them were calm)."""
-    c = (ctypes.c_uint64 * 2)()
+def semiglobal_window_stats(stream=0, walk=False):
+    """(windows of 8 rounds the sweep wavefronts of the last device call on `stream` ran, how many of them were calm); with
+    walk=True also (windows of 16 rounds the traceback wavefronts walked, how many of them twice: a walk left cells 8 .. 23)."""
+    c = (ctypes.c_uint64 * 4)()
     _check(load().swmi_semiglobal_window_stats(ctypes.c_void_p(stream), c))
-    return int(c[0]), int(c[1])
+    return (int(c[0]), int(c[1]), int(c[2]), int(c[3])) if walk else (int(c[0]), int(c[1]))
 
 
 def semiglobal_kernels_for_batch(n):

@@ -70,9 +70,9 @@ def test_argument_errors_do_not_need_a_device(swmi_mod):
         assert lib.swmi_semiglobal_set_mapping(ok) == swmi_mod.OK
     assert lib.swmi_semiglobal_set_exact(2) == swmi_mod.ERR_INVALID_ARGUMENT and lib.swmi_semiglobal_set_exact(-1) == swmi_mod.ERR_INVALID_ARGUMENT
     assert lib.swmi_semiglobal_set_exact(1) == swmi_mod.OK and lib.swmi_semiglobal_set_exact(0) == swmi_mod.OK
-    counts = (ctypes.c_uint64 * 2)(7, 7)
+    counts = (ctypes.c_uint64 * 4)(7, 7, 7, 7)
     assert lib.swmi_semiglobal_window_stats(None, None) == swmi_mod.ERR_INVALID_ARGUMENT
-    assert lib.swmi_semiglobal_window_stats(None, counts) != swmi_mod.OK and list(counts) == [0, 0]       # no device: refused, counters zeroed
+    assert lib.swmi_semiglobal_window_stats(None, counts) != swmi_mod.OK and list(counts) == [0, 0, 0, 0]  # no device: refused, counters zeroed
 
 
 def test_c_shard_rule_is_the_python_shard_rule(swmi_mod):

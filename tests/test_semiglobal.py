@@ -444,3 +444,57 @@ def test_gpu_semiglobal_calm_windows_change_nothing(gpu, oracle, sg_kernels, swe
         words = np.zeros(gpu.SG_MOVE_WORDS, np.uint64)
         words[: len(m2[k])] = m2[k].view(np.uint64)
         assert np.array_equal(gpu.semiglobal_expand_moves(words, int(l2[k])), want_tb), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", [41, 11])
+def test_gpu_semiglobal_walks_outside_the_band_centre(gpu, oracle, sg_kernels, sweep):
+    """The traceback fetches the predecessor records of band cells 8 .. 23 only and, when a walk of its wavefront leaves those
+    cells in a window, decodes the window a second time with the other half (sg_kernels.hip, walk_window).  Relatives with
+    5 % substitutions stay in the centre but for the first windows; sequences that start shifted against each other, or are
+    rich in insertions and deletions, do not -- and come out as the oracle has them."""
+    import torch
+    sg_kernels(sweep)
+    rng = np.random.default_rng(5100 + sweep)
+    n = 64
+    a = rng.integers(0, 4, (n, 16384), dtype=np.uint8)
+    calm = a.copy()
+    subs = rng.random((n, 16384)) < 0.05
+    calm[subs] = (calm[subs] + rng.integers(1, 4, int(subs.sum()), dtype=np.uint8)) & 3
+    wild = calm.copy()
+    for k in range(n):
+        if k % 2:                                # the second sequence starts 3 .. 30 bases into the first one, or the other way round
+            sh = 3 + (k * 7) % 28
+            wild[k] = np.concatenate([calm[k, sh:], rng.integers(0, 4, sh, dtype=np.uint8)]) if k % 4 == 1 else \
+                np.concatenate([rng.integers(0, 4, sh, dtype=np.uint8), calm[k, : 16384 - sh]])
+        else:                                    # bursts of deletions: the path jumps across the band
+            out, i = [], 0
+            while len(out) < 16384:
+                if i < 16384 and rng.random() < 0.004:
+                    i += int(rng.integers(4, 14))
+                out.append(a[k, i] if i < 16384 else rng.integers(0, 4))
+                i += 1
+            wild[k] = out
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream()
+
+    def run(x, y):
+        m = len(x)
+        d1, d2 = torch.from_numpy(x.copy()).to(dev), torch.from_numpy(y.copy()).to(dev)
+        d_scores = torch.empty(m, dtype=torch.int32, device=dev)
+        d_len = torch.empty(m, dtype=torch.int32, device=dev)
+        d_tb = torch.zeros((m, gpu.SG_MAX_TRACEBACK, 2), dtype=torch.int32, device=dev)
+        gpu.semiglobal_xdrop_device(d1.data_ptr(), d2.data_ptr(), m, d_scores.data_ptr(), d_tb.data_ptr(), gpu.SG_MAX_TRACEBACK, d_len.data_ptr(), st.cuda_stream)
+        stats = gpu.semiglobal_window_stats(st.cuda_stream, walk=True)
+        return d_scores.cpu().numpy(), d_len.cpu().numpy(), d_tb.cpu().numpy(), stats
+    s0, l0, t0, (_, _, walked0, again0) = run(a, calm)
+    assert walked0 > 0 and again0 <= 0.02 * walked0
+    s1, l1, t1, (_, _, walked1, again1) = run(a, wild)
+    assert again1 > 0.05 * walked1                # the second decoding is exercised ...
+    for k in range(n):                            # ... and right
+        want_score, want_tb = oracle.semiglobal(a[k], wild[k])
+        assert int(s1[k]) == want_score and int(l1[k]) == len(want_tb), k
+        assert np.array_equal(t1[k, : len(want_tb)], want_tb), k
+    for k in range(0, n, 9):
+        want_score, want_tb = oracle.semiglobal(a[k], calm[k])
+        assert int(s0[k]) == want_score and np.array_equal(t0[k, : int(l0[k])], want_tb), k
