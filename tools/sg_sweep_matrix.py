@@ -19,6 +19,10 @@ for n in sizes:
     keep = torch.rand((n, L), device=dev, generator=g) < 0.95
     d2 = torch.where(keep, d1, rnd).contiguous()
     del rnd, keep
+    if os.environ.get("SG_MATRIX_SHIFTED"):              # every second alignment starts 3 .. 30 bases into the other sequence: paths
+        for sh in range(3, 31):                           # off the band's centre (the traceback's second decoding)
+            rows = torch.arange(sh - 3, n, 56, device=dev)
+            d2[rows] = torch.roll(d2[rows], -sh, dims=1)
     scores = torch.empty(n, dtype=torch.int32, device=dev)
     lengths = torch.empty(n, dtype=torch.int32, device=dev)
     tb = torch.empty((n, cap, 2), dtype=torch.int32, device=dev)
@@ -33,7 +37,8 @@ for n in sizes:
         a, b = swmi.semiglobal_time_device(d1.data_ptr(), d2.data_ptr(), n, scores.data_ptr(), tb.data_ptr(), cap, lengths.data_ptr(), st)
         chk = (int(scores.sum().item()), int(lengths.sum().item()), int(tb[:: max(1, n // 64), :4096].sum().item()))
         ref = ref or chk
-        print("n %7d sweep %2d: sweep %8.2f ms traceback %8.2f ms  -> %8.1f k alignments/s %s" % (
-            n, sweep, a, b, n / (a + b), "" if chk == ref else "MISMATCH"), flush=True)
+        w = swmi.semiglobal_window_stats(st, walk=True)
+        print("n %7d sweep %2d: sweep %8.2f ms traceback %8.2f ms  -> %8.1f k alignments/s %s  (calm %.3f, walked twice %.3f)" % (
+            n, sweep, a, b, n / (a + b), "" if chk == ref else "MISMATCH", w[1] / max(1, w[0]), w[3] / max(1, w[2])), flush=True)
     del d1, d2, tb
     torch.cuda.empty_cache()
