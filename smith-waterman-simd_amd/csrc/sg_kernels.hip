@@ -321,9 +321,9 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
         // the centre words and the outer words are staged apart, 16 rounds per alignment in a row: four lanes take one
         // alignment's row, four rounds each -- 16 alignments x 64 B of centre words, then of outer words, per pair of store
-        // instructions; neighbouring lanes take neighbouring ALIGNMENTS (rows 80 bytes = 20 banks apart).  (Staged as
-        // (centre, outer) pairs the words had to be parted in registers: 32 moves per flush.)
-        const int fa16 = lane & 15, part = lane >> 4;
+        // instructions, eight neighbouring lanes per 128-byte line.  (Staged as (centre, outer) pairs the words had to be
+        // parted in registers: 32 moves per flush.)
+        const int fa16 = lane >> 2, part = lane & 3;
         uint4 vc[A / 16], vo[A / 16];
         auto fetch = [&](int q) {
             vc[q] = *reinterpret_cast<const uint4 *>(&stage_codes[0][q * 16 + fa16][4 * part]);
@@ -664,9 +664,9 @@ sg_forward_lane_kernel(const unsigned long long *__restrict__ streams, uint32_t 
         // (the flush after the last round, once per wavefront, goes row by row: it has no registers to spare for the rows)
         // the centre words and the outer words are staged apart, 16 rounds per alignment in a row: four lanes take one
         // alignment's row, four rounds each -- 16 alignments x 64 B of centre words, then of outer words, per pair of store
-        // instructions; neighbouring lanes take neighbouring ALIGNMENTS (rows 80 bytes = 20 banks apart).  (Staged as
-        // (centre, outer) pairs the words had to be parted in registers: 32 moves per flush.)
-        const int fa16 = lane & 15, part = lane >> 4;
+        // instructions, eight neighbouring lanes per 128-byte line.  (Staged as (centre, outer) pairs the words had to be
+        // parted in registers: 32 moves per flush.)
+        const int fa16 = lane >> 2, part = lane & 3;
         uint4 vc[A / 16], vo[A / 16];
         auto fetch = [&](int q) {
             vc[q] = *reinterpret_cast<const uint4 *>(&stage_codes[0][q * 16 + fa16][4 * part]);
