@@ -262,12 +262,22 @@ def score_pair(seq1, seq2, score_matrix, gap_penalty):
     return _check(load().swmi_score_pair(a.ctypes.data, b.ctypes.data, sm.ctypes.data, _gap(gap_penalty)))
 
 
-def score_batch(seq1s, seq2s, score_matrix, gap_penalty):
+def _scores_out(out, n):
+    """The result array of a host entry: a fresh one, or the caller's (C-contiguous int32[n]) -- a fresh array's pages are
+    first touched by the copy that fills them, inside the call."""
+    if out is None:
+        return np.zeros(n, np.int32)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.int32 and out.flags.c_contiguous and out.size == n):
+        raise ValueError("out must be a C-contiguous int32 array of %d scores" % n)
+    return out
+
+
+def score_batch(seq1s, seq2s, score_matrix, gap_penalty, out=None):
     a, b, sm = _u8(seq1s, SEQ_LEN), _u8(seq2s, SEQ_LEN), _sm(score_matrix)
     if a.shape != b.shape:
         raise ValueError("seq1s and seq2s must have the same shape")
     n = a.size // SEQ_LEN
-    out = np.zeros(n, np.int32)
+    out = _scores_out(out, n)
     _check(load().swmi_score_batch(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
 
@@ -356,18 +366,18 @@ class ShardedBatch:
             pass
 
 
-def score_one_vs_many(seq1s, seq2, score_matrix, gap_penalty):
+def score_one_vs_many(seq1s, seq2, score_matrix, gap_penalty, out=None):
     a, b, sm = _u8(seq1s, SEQ_LEN), _u8(seq2, SEQ_LEN), _sm(score_matrix)
     n = a.size // SEQ_LEN
-    out = np.zeros(n, np.int32)
+    out = _scores_out(out, n)
     _check(load().swmi_score_one_vs_many(a.ctypes.data, n, b.ctypes.data, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
 
 
-def score_batch_packed(seq1s_packed, seq2s_packed, score_matrix, gap_penalty):
+def score_batch_packed(seq1s_packed, seq2s_packed, score_matrix, gap_penalty, out=None):
     a, b, sm = _u8(seq1s_packed, PACKED_LEN), _u8(seq2s_packed, PACKED_LEN), _sm(score_matrix)
     n = a.size // PACKED_LEN
-    out = np.zeros(n, np.int32)
+    out = _scores_out(out, n)
     _check(load().swmi_score_batch_packed(a.ctypes.data, b.ctypes.data, n, sm.ctypes.data, _gap(gap_penalty), out.ctypes.data))
     return out
 
