@@ -137,6 +137,23 @@ def test_gpu_semiglobal_small_cap_and_empty(gpu, oracle, sg_kernels, sweep):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sweep", [4, 2, 1])
+def test_gpu_semiglobal_ragged_batches(gpu, golden, sg_kernels, sweep):
+    """Batches of 1, 3 and 65 alignments: the lanes of a sweep wavefront (and the rows of its record flush) past the last
+    alignment shadow that alignment -- they store its records on top of its own, the same bytes -- and a walk wavefront's
+    tail lanes store nothing.  Results as in the fixture, whatever stands beside an alignment."""
+    sg_kernels(sweep)
+    f = golden("f6_semiglobal")
+    paths = _paths_from_fixture(f)
+    reps = np.arange(65) % len(paths)
+    for n in (1, 3, 65):
+        scores, tbs, lengths = gpu.semiglobal_xdrop(f["seq1"][reps[:n]], f["seq2"][reps[:n]])
+        assert np.array_equal(scores, f["scores"][reps[:n]])
+        for k in range(n):
+            assert np.array_equal(tbs[k], paths[reps[k]]), (n, k)
+
+
+@pytest.mark.gpu
 def test_gpu_semiglobal_phase_timing_entry(gpu, oracle):
     """swmi_semiglobal_time_device: same results as the plain device call, two positive kernel durations."""
     import torch
