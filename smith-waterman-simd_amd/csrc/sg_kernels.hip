@@ -415,8 +415,12 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         const int rmask = keep_opaque((int)((unsigned)group_first(cur[0]) & 0xFFFFu) - (int)((unsigned)group_last(cur[NV - 1]) >> 16)) >> 31;
         pos_x -= rmask;                                   // += 1 when the band steps right
         dir_word = __builtin_amdgcn_alignbit((unsigned)rmask, dir_word, 1);   // (dir_word >> 1) | (right << 31)
-        const int pos_y = round - (pos_x - 31);
-        alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;    // :1903, :1913: both still inside
+        // :1903, :1913: both still inside.  (Not asked in a calm round: every character such a window takes from the streams
+        // is a base, i.e. lies inside its sequence -- pos_y + 30 < kLen and pos_x - 32 < kLen after the step -- far from these limits.)
+        if constexpr (!kCalm) {
+            const int pos_y = round - (pos_x - 31);
+            alive_m &= (keep_opaque(pos_x - (32 + kLen + 31 + 1)) & keep_opaque(pos_y - (1 + kLen + 1))) >> 31;
+        }
         // neighbours of the slice in the previous round's band
         // register "-1" = cells (-1, NV - 1), register "NV" = cells (NV, C): the neighbour lane's end cell in one half, this
         // lane's own middle cell in the other (0 = dropped past the band's ends)
@@ -566,8 +570,8 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
     // a gap step adds 0), while the threshold climbs by one per round plus the rise of `best`, which is at most one per two
     // rounds (a diagonal step takes two) -- 12 in 8 rounds.  Those rounds then run without the X-drop test (one v_and per
     // register instead of compare, mask, apply) and without the guards for a dropped band maximum: the same results by
-    // construction.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of every alignment) or
-    // exact_only send the window down the exact path.  Two loops, one per kind of window, each running for as long as its
+    // construction.  A band next to its threshold, a dropped cell anywhere in it (the first rounds of every alignment), a pad
+    // in reach or exact_only send the window down the exact path.  Two loops, one per kind of window, each running for as long as its
     // kind lasts: hipcc gives the two bodies different register assignments, and the moves between them are paid only where
     // the kind changes.  ("Has every alignment of the wavefront ended" is asked at the same place, not per round: a vector
     // compare feeding a scalar branch drains the wavefront's pipeline; the rounds a finished wavefront runs on change nothing
@@ -582,7 +586,11 @@ sg_forward_split_kernel(const unsigned long long *__restrict__ streams, uint32_t
         else                   low = sg_pk_min3(sg_pk_min3((unsigned)cur[0], (unsigned)cur[1], (unsigned)cur[2]), (unsigned)cur[3], (unsigned)cur[3]);
         const int low_stored = (int)min(low & 0xFFFFu, low >> 16) >> 7;
         const int thr_now = (best - kXDrop > 1 ? best - kXDrop : 1) - off;
-        const bool edgy = alive_m != 0 && low_stored < thr_now + kCalmMargin;
+        // ... and bases only, in the slice's windows and among the at most 8 characters the window takes from the stream (a
+        // pad of the matrix's edges or a byte that was not 0..3 has bit 2 set): the position tests are then idle, see one_round
+        const unsigned long long w64 = (unsigned long long)(aw | bw) | (feed.sreg >> feed.used4 & 0xFFFFFFFFull);
+        const unsigned fields = (unsigned)w64 | (unsigned)(w64 >> 32);
+        const bool edgy = alive_m != 0 && (low_stored < thr_now + kCalmMargin || (fields & 0x44444444u) != 0);
         return !exact_only && !__any(edgy) ? 1 : 0;
     };
     int round = 1, kind = window_kind();
@@ -1394,17 +1402,17 @@ struct SweepBuild {
     float part[3];               // a last turn of 1 .. W - 1 wavefronts per SIMD
 };
 constexpr SweepBuild kSweepBuilds[] = {
-    {41, 4, 1, 7.7f, {0, 0, 0}},
-    {21, 2, 1, 10.0f, {0, 0, 0}},
-    {23, 2, 3, 25.7f, {17.6f, 17.6f, 0}},
-    {11, 1, 1, 15.3f, {0, 0, 0}},
-    {12, 1, 2, 26.7f, {13.0f, 0, 0}},            // (a batch of ONE wavefront per SIMD on this build: 26.6 -- never chosen: 11 is there)
+    {41, 4, 1, 7.05f, {0, 0, 0}},
+    {21, 2, 1, 9.75f, {0, 0, 0}},
+    {22, 2, 2, 17.0f, {7.8f, 0, 0}},             // (a batch of ONE wavefront per SIMD on this build: 16.5 -- 21 is there for it)
+    {11, 1, 1, 14.6f, {0, 0, 0}},
+    {12, 1, 2, 25.9f, {12.0f, 0, 0}},            // (the same: 25.2 -- 11 is there)
 };
 int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
 {
     if (tuning.force_sweep >= 0) {
         const int s = tuning.force_sweep;
-        return s == 4 ? 44 : s == 2 ? 23 : s == 1 ? 12 : s;
+        return s == 4 ? 44 : s == 2 ? 22 : s == 1 ? 12 : s;
     }
     const size_t simds = (size_t)(compute_units > 0 ? compute_units : 256) * 4;     // (a partitioned gfx950 reports fewer CUs)
     int best = 41;
@@ -1414,7 +1422,7 @@ int choose_sweep(size_t n, int compute_units, const SgTuning &tuning)
         const int w = (int)((wavefronts + simds - 1) / simds);
         const int turns = w / b.waves, rest = w % b.waves;
         float t = turns * b.full + (rest ? b.part[rest - 1] : 0.0f);
-        if (b.id == 12 && w == 1) t = 26.6f;
+        if (b.waves == 2 && w == 1) t = b.id == 12 ? 25.2f : 16.5f;
         if (best_t == 0 || t < best_t) {
             best_t = t;
             best = b.id;

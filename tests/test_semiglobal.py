@@ -247,18 +247,18 @@ def test_gpu_semiglobal_mapping_choice_and_argument_check(gpu, swmi_mod):
     half or three wavefronts of 32 alignments); swmi_semiglobal_set_mapping rejects what is no mapping and leaves the setting alone."""
     if gpu.device_info()["compute_units"] == 256:
         want = {1: "sg_forward_split_kernel<4, 1>", 16384: "sg_forward_split_kernel<4, 1>", 32768: "sg_forward_split_kernel<2, 1>",
-                49152: "sg_forward_lane_kernel<1>", 65536: "sg_forward_lane_kernel<1>", 81920: "sg_forward_split_kernel<2, 3>",
-                98304: "sg_forward_split_kernel<2, 3>", 131072: "sg_forward_lane_kernel<2>", 196608: "sg_forward_lane_kernel<2>",
+                49152: "sg_forward_lane_kernel<1>", 65536: "sg_forward_lane_kernel<1>", 81920: "sg_forward_split_kernel<2, 2>",
+                98304: "sg_forward_split_kernel<2, 2>", 131072: "sg_forward_lane_kernel<2>", 196608: "sg_forward_lane_kernel<2>",
                 262144: "sg_forward_lane_kernel<2>"}
         for n, name in want.items():
             assert swmi_mod.semiglobal_kernels_for_batch(n) == (name, "sg_walk_lane_kernel + sg_expand_kernel"), n
     swmi_mod.semiglobal_set_mapping(2)
     try:
-        assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 3>"
+        assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 2>"
         for bad in (0, 3, 5, 13, 14, 20, 24, 45, 101, 221):
             with pytest.raises(swmi_mod.SwmiError):
                 swmi_mod.semiglobal_set_mapping(bad)
-            assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 3>"      # unchanged
+            assert swmi_mod.semiglobal_kernels_for_batch(1000)[0] == "sg_forward_split_kernel<2, 2>"      # unchanged
         swmi_mod.semiglobal_set_mapping(12)
         assert swmi_mod.semiglobal_kernels_for_batch(5)[0] == "sg_forward_lane_kernel<2>"
     finally:
