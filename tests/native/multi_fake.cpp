@@ -167,6 +167,24 @@ int main(int argc, char **argv)
     for (int g = 0; g < 3; ++g) CHECK(swmi_sharded_gathered_host(sb, g, got.data()) == SWMI_OK && counts_up(got));
     CHECK(swmi_sharded_destroy(sb) == SWMI_OK);
 
+    // ---- the semi-global aligner's per-stream workspace and the lifetime of its window counters (the kernels are stand-ins) ----
+    {
+        CHECK(swmi_use_gpu(2) == SWMI_OK);
+        uint64_t counts[4] = {9, 9, 9, 9};
+        CHECK(swmi_semiglobal_window_stats(nullptr, counts) == SWMI_ERR_INVALID_ARGUMENT);       // no call on this stream yet
+        CHECK(strstr(swmi_last_error(), "no semi-global call") && counts[0] == 0 && counts[3] == 0);
+        // (a fake GPU's memory is the host's: any 16-byte aligned buffer is a "device" pointer)
+        void *d1 = aligned_alloc(64, 4 * 16384), *d2 = aligned_alloc(64, 4 * 16384), *ds = aligned_alloc(64, 64), *dl = aligned_alloc(64, 64),
+             *dm = aligned_alloc(64, 4 * SWMI_SG_MOVE_WORDS * 8);
+        CHECK(d1 && d2 && ds && dl && dm);
+        CHECK(swmi_semiglobal_xdrop_moves_device(d1, d2, 4, ds, dm, dl, nullptr) == SWMI_OK);
+        CHECK(swmi_semiglobal_window_stats(nullptr, counts) == SWMI_OK);                            // (whatever the stand-in left there)
+        CHECK(swmi_semiglobal_window_stats(nullptr, nullptr) == SWMI_ERR_INVALID_ARGUMENT);
+        CHECK(swmi_semiglobal_release_workspaces() == SWMI_OK);
+        CHECK(swmi_semiglobal_window_stats(nullptr, counts) == SWMI_ERR_INVALID_ARGUMENT);       // the workspace is gone
+        for (void *q : {d1, d2, ds, dl, dm}) free(q);
+    }
+
     // ---- the host-batch pipeline on one fake GPU: granule order, slots, one score copy at the end ----
     CHECK(swmi_use_gpu(1) == SWMI_OK);
     const size_t big = (size_t(1) << 20) + 12345;
