@@ -10,7 +10,8 @@ bash tools/profile_host_batch.sh $T packed > /dev/null 2>&1
 bash tools/profile_host_batch.sh $T ovm > /dev/null 2>&1
 bash tools/profile_host_batch.sh $T pairs > /dev/null 2>&1
 smith-waterman-simd_amd/bin/swmi_speedtest 1048576 1048576 65536 > gpurun_out/${T}_swmi_speedtest.txt 2>&1
-python3 tools/sg_sweep_matrix.py 1 1024 4096 16384 32768 49152 65536 131072 262144 2>&1 | grep "sweep -1" > gpurun_out/${T}_sg_matrix.txt
+python3 tools/sg_sweep_matrix.py 1 1024 4096 16384 32768 49152 65536 81920 98304 131072 262144 2>&1 | grep "sweep -1" > gpurun_out/${T}_sg_matrix.txt
+SWMI_SG_EXACT=1 python3 tools/sg_sweep_matrix.py 1 16384 32768 65536 131072 262144 2>&1 | grep "sweep -1" > gpurun_out/${T}_sg_matrix_exact.txt
 python3 bench.py --mode banded-affine --steps 20 --warmup 3 > gpurun_out/${T}_bench_banded_affine.json 2>/dev/null
 python3 bench.py > gpurun_out/${T}_bench_default.json 2>/dev/null
 echo profile-all-done
