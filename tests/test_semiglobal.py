@@ -515,3 +515,36 @@ def test_gpu_semiglobal_walks_outside_the_band_centre(gpu, oracle, sg_kernels, s
     for k in range(0, n, 9):
         want_score, want_tb = oracle.semiglobal(a[k], calm[k])
         assert int(s0[k]) == want_score and np.array_equal(t0[k, : int(l0[k])], want_tb), k
+
+
+@pytest.mark.gpu
+def test_gpu_semiglobal_switches_from_the_environment(gpu):
+    """SWMI_SG_SWEEP and SWMI_SG_EXACT give the initial mapping and the exact-only switch of a process (read once, at swmi_init):
+    a child process with both set reports the forced build and runs no calm window; one without them does."""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smith-waterman-simd_amd")
+    code = (
+        "import sys; sys.path.insert(0, %r); import numpy as np, torch, swmi\n"
+        "swmi.init(0)\n"
+        "rng = np.random.default_rng(3); a = rng.integers(0, 4, (4, 16384), dtype=np.uint8)\n"
+        "dev = torch.device('cuda', 0); d1 = torch.from_numpy(a).to(dev); d2 = d1.clone()\n"
+        "s = torch.empty(4, dtype=torch.int32, device=dev); l = torch.empty(4, dtype=torch.int32, device=dev)\n"
+        "m = torch.zeros(4 * swmi.SG_MOVE_WORDS, dtype=torch.int64, device=dev); st = torch.cuda.current_stream().cuda_stream\n"
+        "swmi.semiglobal_xdrop_moves_device(d1.data_ptr(), d2.data_ptr(), 4, s.data_ptr(), m.data_ptr(), l.data_ptr(), st)\n"
+        "w = swmi.semiglobal_window_stats(st)\n"
+        "print(swmi.semiglobal_kernels_for_batch(4)[0]); print(w[0], w[1]); print(s.cpu().tolist())\n" % pkg)
+
+    def run(**env):
+        clean = {k: v for k, v in os.environ.items() if not k.startswith("SWMI_")}
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(clean, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.strip().splitlines()
+        return lines[-3], [int(x) for x in lines[-2].split()], lines[-1]
+    kernel, (windows, calm), scores = run()
+    assert kernel == "sg_forward_split_kernel<4, 1>" and windows > 0 and calm > 0.9 * windows and scores == "[16384, 16384, 16384, 16384]"
+    kernel, (windows2, calm2), scores2 = run(SWMI_SG_SWEEP="22", SWMI_SG_EXACT="1")
+    assert kernel == "sg_forward_split_kernel<2, 2>" and windows2 > 0 and calm2 == 0 and scores2 == scores
+    kernel, (_, calm3), _ = run(SWMI_SG_SWEEP="13", SWMI_SG_EXACT="7")      # values the setters would reject are ignored
+    assert kernel == "sg_forward_split_kernel<4, 1>" and calm3 > 0
