@@ -180,6 +180,28 @@ __global__ void __launch_bounds__(256) expand_flat_shape_kernel(v4u *__restrict_
     for (int q = 0; q < STORES; ++q) __builtin_nontemporal_store(v, out + 64 * q + lane);
 }
 
+// ... and the one-shot form WITH a checkpoint: one wavefront per 1 KB chunk reads one 8-byte checkpoint and 64 bytes of the
+// region's move words (what it would need to place itself: a running position every 128 moves from the walk + the moves
+// between it and the chunk) and writes its kilobyte.
+__global__ void __launch_bounds__(256) expand_chk_shape_kernel(v4u *__restrict__ dst, const unsigned long long *__restrict__ moves,
+                                                               size_t region16, unsigned value)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (size_t)blockIdx.x * 4 + wv;
+    const size_t r = wave / 128;
+    const int j = (int)(wave % 128);
+    const unsigned long long *mine = moves + r * 664;    // 4160 bytes of moves + 130 checkpoints of 8 bytes per region
+    const unsigned long long chk = mine[520 + j];
+    const unsigned long long w = lane < 8 ? mine[4 * j + (lane & 7)] : 0ull;
+    unsigned red = (unsigned)__popcll(w) + (unsigned)(chk & 0xFFFF);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x111, 0xf, 0xf, true);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x112, 0xf, 0xf, true);
+    red += (unsigned)__builtin_amdgcn_update_dpp(0, (int)red, 0x114, 0xf, 0xf, true);
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)red, 7);
+    const v4u v = {value + tot, value + 1, value + 2, value + 3};
+    __builtin_nontemporal_store(v, dst + r * region16 + (size_t)j * 64 + lane);
+}
+
 static double time_ms(hipStream_t st, int reps, const std::function<void()> &launch)
 {
     hipEvent_t a, b;
@@ -286,6 +308,10 @@ int main(int argc, char **argv)
         FLAT_CASE(1, true, "expand shape: one wavefront per 1 KB chunk, prefix from moves")
         FLAT_CASE(1, false, "expand shape: one wavefront per 1 KB chunk, no prefix")
 #undef FLAT_CASE
+        ms = time_ms(st, 9, [&] { hipLaunchKernelGGL(expand_chk_shape_kernel, dim3((unsigned)(regions * 128 / 4)), dim3(256), 0, st, a,
+                                                     reinterpret_cast<const unsigned long long *>(b), region / 16, 7u); });
+        printf("%-60s %8.3f ms  %6.2f TB/s\n", "expand shape: one wavefront per 1 KB chunk, checkpoint + 8 words", ms, moved / ms / 1e9);
+        fflush(stdout);
     }
     CHECK(hipFree(a));
     CHECK(hipFree(b));
