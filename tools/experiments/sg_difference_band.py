@@ -1,0 +1,118 @@
+"""The adaptive band of the reference's semi-global aligner (source.cpp:1895-1946) carried as DIFFERENCES instead of values, round by
+round, with the band's data-dependent step and its two ends -- checked against the plain band sweep (a Python transcript of
+oracle/sg_oracle.c) wherever every cell of the band is alive (the GPU sweeps' calm windows).  numpy only; spec work for a
+difference-encoded calm loop, nothing here is shipped.
+
+State of a round r (cell k of the band at row pos_y + 31 - k, column pos_x - 62 + k):
+    dH[k] = G(cell) - G(its left neighbour), dV[k] = G(cell) - G(its upper neighbour),   G = value + round  (0 .. 3 each)
+    lo = G(cell 0), hi = G(cell 31)       (the band steps right when lo < hi, :1895)
+Step to round r + 1, direction known:
+    right: cell k's left neighbour is old cell k, its upper one old cell k + 1 (none for k = 31), its diagonal the upper
+           neighbour of old cell k;   down: upper = old cell k, left = old cell k - 1 (none for k = 0), diagonal = the left
+           neighbour of old cell k.
+    h = dH[old upper], v = dV[old left], d = 3 on a match else 1;  m = max(d, h, v);  dV' = m - h, dH' = m - v;
+    tag = 3 (diagonal) if d == m else 2 (up) if h == m else 1 (left).
+    A missing neighbour takes part with difference 0 (d >= 1 beats it); where the DIAGONAL is missing too -- cell 31 after two
+    steps right, cell 0 after two steps down -- the one neighbour there is wins with difference 0.
+"""
+import ctypes, os, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+X, BAND, LEN = 70, 32, 16384
+
+
+def plain_band(a, b, rounds):
+    """cur[r][k] (value + 70, 0 = dropped), direction (1 = right) and tag per round, as oracle/sg_oracle.c computes them."""
+    cur = np.zeros(BAND, int); hor = np.zeros(BAND, int); ver = np.zeros(BAND, int); dia = np.zeros(BAND, int)
+    cur[31] = X
+    pos_y, pos_x, best = 0, 31, X
+    out = []
+    for r in range(1, rounds + 1):
+        right = cur[0] < cur[31]
+        if right:
+            dia = ver.copy(); hor = cur.copy(); ver = np.append(cur[1:], 0); pos_x += 1
+        else:
+            dia = hor.copy(); ver = cur.copy(); hor = np.insert(cur[:-1], 0, 0); pos_y += 1
+        new = np.zeros(BAND, int); tag = np.zeros(BAND, int); match = np.zeros(BAND, int)
+        for k in range(BAND):
+            y, x = pos_y + 31 - k, pos_x - 62 + k
+            c1 = a[y - 1] if 1 <= y <= LEN else 0xF0
+            c2 = b[x - 1] if 1 <= x <= LEN else 0xF1
+            s = 1 if (c1 < 4 and c1 == c2) else -1
+            match[k] = s == 1
+            v, t = 0, 0
+            if dia[k] and dia[k] + s > v: v, t = dia[k] + s, 3
+            if ver[k] and ver[k] - 1 > v: v, t = ver[k] - 1, 2
+            if hor[k] and hor[k] - 1 > v: v, t = hor[k] - 1, 1
+            new[k], tag[k] = v, t
+        best = max(best, new.max())
+        new[new < best - X] = 0
+        cur = new
+        out.append((cur.copy(), int(right), tag.copy(), match.copy(), hor.copy(), ver.copy(), dia.copy()))
+        if cur.max() == 0:
+            break
+    return out
+
+
+def check(a, b, rounds=3000):
+    rows = plain_band(a, b, rounds)
+    checked = carried = 0
+    state = None                                          # (dH, dV, lo, hi): CARRIED from round to round once seeded
+    prev_right = None
+    for r, (cur, right, tag, match, hor, ver, dia) in enumerate(rows, start=1):
+        G = cur + r                                       # (the +70 offset cancels in every difference)
+        tH = np.where(hor > 0, G - (hor + r - 1), -1)     # ground truth (against the neighbours as the plain sweep saw them)
+        tV = np.where(ver > 0, G - (ver + r - 1), -1)
+        calm = cur.min() > 0 and hor[1:].min() > 0 and ver[:-1].min() > 0
+        if state is not None and calm:
+            dH, dV, lo, hi = state
+            assert (lo < hi) == bool(right), r            # the band's step from the two carried end values (:1895)
+            if right:
+                h = np.append(dH[1:], 0); v = dV.copy()
+                no_diag = 31 if prev_right == 1 else None
+            else:
+                h = dH.copy(); v = np.insert(dV[:-1], 0, 0)
+                no_diag = 0 if prev_right == 0 else None
+            if not all(dia[k] > 0 for k in range(BAND) if k != no_diag):
+                state = None                              # (a cell of two rounds ago was dropped: not a calm stretch yet)
+            else:
+                d = np.where(match == 1, 3, 1)
+                m = np.maximum(d, np.maximum(h, v))
+                nV, nH = m - h, m - v
+                t = np.where(d == m, 3, np.where(h == m, 2, 1))
+                if no_diag is not None:                   # only one neighbour exists there: it wins, difference 0
+                    if right: nH[31], t[31] = 0, 1
+                    else:     nV[0], t[0] = 0, 2
+                assert np.array_equal(t, tag), (r, t, tag)
+                assert np.array_equal(nH[tH >= 0], tH[tH >= 0]) and np.array_equal(nV[tV >= 0], tV[tV >= 0]), r
+                assert nH.min() >= 0 and nV.min() >= 0 and max(nH.max(), nV.max()) <= 3
+                # the ends: cell 0 keeps its left neighbour on a step right (old cell 0), its upper one on a step down (old cell 0)
+                lo = lo + (nH[0] if right else nV[0])
+                hi = hi + (nH[31] if right else nV[31])
+                assert lo == G[0] and hi == G[31], r
+                state = (nH, nV, lo, hi)                  # carried: the entries against missing neighbours are never read
+                checked += 1
+                carried += 1
+                prev_right = right
+                continue
+        # (re)seed from the plain sweep where the stretch is not calm
+        state = (np.where(tH >= 0, tH, 0), np.where(tV >= 0, tV, 0), G[0], G[31]) if cur.min() > 0 else None
+        prev_right = right
+    return checked, len(rows)
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(11)
+    total = 0
+    for trial in range(6):
+        a = rng.integers(0, 4, LEN).astype(np.uint8)
+        p = (0.02, 0.05, 0.1, 0.2, 0.05, 0.3)[trial]
+        b = np.where(rng.random(LEN) < p, rng.integers(0, 4, LEN), a).astype(np.uint8)
+        if trial >= 4:                                    # insertions / deletions: the band steps unevenly
+            cut, sh = int(rng.integers(200, 1500)), int(rng.integers(1, 12))
+            b[cut:] = np.roll(b, sh)[cut:]
+        checked, rounds = check(a, b)
+        total += checked
+        print("trial %d: %d of %d rounds carried in differences and equal to the plain band (tags, dH, dV)" % (trial, checked, rounds))
+    assert total > 10000
