@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes run swmi/sharding.py -- shard_bounds, gather_scores and the
+"""The N > 1 path on CPU: world_size-2 (and -8) gloo processes run swmi/sharding.py -- shard_bounds, gather_scores and the
 GatherPipeline, the very code bench.py --gpus N runs -- with the CPU oracle standing in for the GPU scorer (this test
 checks host logic only): gather after every step (asynchronous, ring of buffers) and one final gather, equal and
 ragged shards."""
@@ -50,6 +50,19 @@ def _worker(rank, world, port, n_total, out_dir, mode, steps):
 @pytest.mark.parametrize("n_total,mode,steps", [(4096, "final", 1), (4097, "final", 1), (4096, "every", 6), (4097, "every", 3)])
 def test_two_rank_shard_and_gather(tmp_path, oracle, n_total, mode, steps):
     world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), mode, steps), nprocs=world, join=True)
+    a, b = oracle.generate(n_total, 10000, 0)
+    want = oracle.batch(a, b, match_matrix(10, -30), 15)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got, want), "rank %d" % r
+
+
+@pytest.mark.parametrize("n_total,mode,steps", [(4099, "every", 3), (5, "final", 1)])
+def test_eight_rank_shard_and_gather(tmp_path, oracle, n_total, mode, steps):
+    """The size the driver's scaling run ends at: eight ranks, ragged shards (4099 = 3 x 513 + 5 x 512), and fewer pairs than
+    ranks (three ranks with an empty shard take part in the gathers all the same)."""
+    world = 8
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), mode, steps), nprocs=world, join=True)
     a, b = oracle.generate(n_total, 10000, 0)
     want = oracle.batch(a, b, match_matrix(10, -30), 15)
